@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 16-frame 128x128 videos / second for a 100-step D3PM sample (BASELINE.json).
+
+A "step" = one pass of the hot path over one batch: the full 100-step classifier-free-guided reverse
+loop over a 16x16x16 token grid for `--batch` clips (config C3: bs 16, guidance 2, 19-layer denoiser,
+K = 4096) followed by the VQ-VAE decode of those clips to (3,16,128,128).  Synthetic data, random-init
+weights of the reference architecture.  One process per GPU; ranks sample independent clips (weak scaling,
+no data-path collective).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+import gsdd_amd  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_models(args, device):
+    torch.manual_seed(0)
+    L = args.grid[0] * args.grid[1] * args.grid[2]
+    side = 1
+    while side * side < L:
+        side *= 2
+    dalle = gsdd_amd.DalleMaskImageEmbedding(num_embed=args.codes, spatial_size=[side, side], embed_dim=64)
+    tr = gsdd_amd.Text2ImageTransformer(dalle=dalle, condition_seq_len=77, n_layer=args.layers, n_embd=64, n_head=16,
+                                        content_seq_len=L, mlp_hidden_times=4, block_activate="GELU2",
+                                        attn_type="selfcross", content_spatial_size=[side, side], condition_dim=512,
+                                        diffusion_step=args.diffusion_steps, timestep_type="adalayernorm")
+    dm = gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=args.diffusion_steps, alpha_init_type="alpha1",
+                                       auxiliary_loss_weight=5.0e-4, adaptive_auxiliary_loss=True, mask_weight=[1, 1],
+                                       learnable_cf=False, guidance_scale=2, content_seq_len=L)
+    frames, res = args.grid[0], args.grid[1] * 8
+    vq = gsdd_amd.VQVAE(None, 128, args.codes, 256, 3, [1, 8, 8], frames, res)
+    return dm.to(device).eval(), vq.to(device).eval(), L
+
+
+def attention_roofline(B2, L, H, device, iters=10):
+    """Dominant kernel (self-attention, head dim 4) timed alone with HIP events on its launch stream."""
+    M = B2 * L
+    q = torch.randn((3 * H, M, 4), device=device)
+    out = torch.empty((M, H * 4), device=device)
+    st = torch.cuda.current_stream()
+    for _ in range(2):
+        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, stream=st)
+    e0, e1 = gsdd_amd.ops.Event(), gsdd_amd.ops.Event()
+    e0.record(st)
+    for _ in range(iters):
+        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, stream=st)
+    e1.record(st)
+    ms = e0.elapsed_ms(e1) / iters
+    flops = 16.0 * L * L * H * B2            # QK^T (2*4) + PV (2*4) per score
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "d3pm_attention_kernel", "achieved": round(tf, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": None, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+
+
+def cpu_baseline(args, dm, vq, L):
+    """The CPU oracle (our restatement of the reference path, torch-CPU ops) on a bounded sample:
+    one guided reverse step at B=1 (2 denoiser passes + posterior + Gumbel) and one decode, extrapolated
+    to a whole video = diffusion_steps reverse steps + 1 decode."""
+    from oracle import d3pm as od, vqvae as ov
+    sd = {k: v.detach().cpu() for k, v in dm.state_dict().items()}
+    vsd = {k: v.detach().cpu() for k, v in vq.state_dict().items()}
+    cfg = dict(downsample=[1, 8, 8], n_res_layers=3)
+    K = args.codes
+    T = args.diffusion_steps
+    g = torch.Generator().manual_seed(1)
+    tok = torch.randint(0, K, (1, L), generator=g)
+    tok[torch.rand(1, L, generator=g) < 0.5] = K
+    cond = torch.randn(1, 1, 512, generator=g)
+    t = torch.full((1,), T // 2, dtype=torch.long)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        od.p_sample_step(tok, cond, torch.zeros_like(cond), t, sd, 2.0, None, 0)
+        t_step = time.perf_counter() - t0
+        codes = torch.randint(0, K, (1,) + tuple(args.grid), generator=g)
+        t0 = time.perf_counter()
+        ov.decode(codes, vsd, cfg)
+        t_dec = time.perf_counter() - t0
+    per_video = T * t_step + t_dec
+    return {"value": 1.0 / per_video, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 guided reverse step at B=1 L={L} ({t_step:.2f} s) x{T} + 1 decode ({t_dec:.2f} s), "
+                      "torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU per step (config C3: 16)")
+    ap.add_argument("--grid", type=int, nargs=3, default=[16, 16, 16], help="latent token grid t h w")
+    ap.add_argument("--codes", type=int, default=4096)
+    ap.add_argument("--layers", type=int, default=19)
+    ap.add_argument("--diffusion-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    dm, vq, L = build_models(args, device)
+    B = args.batch
+    texts = ["synthetic"] * B
+    g = torch.Generator().manual_seed(100 + rank)
+    cond = torch.randn(B, 1, 512, generator=g).to(device)          # general conditioning (not the zeroed case)
+    cf_cond = torch.zeros(B, 1, 512, device=device)
+    dm.set_noise(1234, 0, row_offset=rank * B)
+
+    def one_pass():
+        out = dm.sample(texts, None, cond, cf_cond, content_token=None, filter_ratio=0, use_graph=not args.no_graph)
+        clips = vq.decode(out["content_token"].view(B, *args.grid))
+        return clips
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        clips = one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        clips = one_pass()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert tuple(clips.shape) == (B, 3, args.grid[0], args.grid[1] * 8, args.grid[2] * 8)
+    assert torch.isfinite(clips).all()
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank == 0:
+        value = B * world * args.steps / dt
+        line = {
+            "metric": "16-frame 128x128 videos/sec, 100-step D3PM sample", "value": round(value, 4),
+            "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: D3PM {args.diffusion_steps}-step p_sample, guidance 2, "
+                                   f"{args.grid[0]}x{args.grid[1]}x{args.grid[2]} token grid, K={args.codes}, "
+                                   f"{args.layers} layers, bs {B}/GPU + VQ-VAE decode to 3x{args.grid[0]}x"
+                                   f"{args.grid[1] * 8}x{args.grid[2] * 8}",
+                       "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
+                       "hipgraph": not args.no_graph},
+        }
+        line["roofline"] = attention_roofline(2 * B, L, 16, device)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, dm, vq, L)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""ctypes binding of libgsdd.so (include/gsdd.h).  No fallback: a missing library is a hard error
+the moment any operator is used (importing the package on a box without the .so still works so that
+CPU-only host logic — configs, weight repacking — can be tested)."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsdd.so")
+_lib = None
+
+EXPORTS = [
+    "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
+    "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
+    "gsdd_d3pm_attention", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_advance",
+    "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
+    "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
+]
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("in_", _p), ("N", _i), ("Di", _i), ("Hi", _i), ("Wi", _i), ("Cin", _i), ("in_pitch", _i),
+        ("Do", _i), ("Ho", _i), ("Wo", _i), ("sd", _i), ("sh", _i), ("sw", _i),
+        ("ntaps", _i), ("taps", _p), ("gather", _p),
+        ("w", _p), ("Cout", _i),
+        ("pro_scale", _p), ("pro_shift", _p), ("ln_stats", _p), ("ln_gamma", _p), ("ln_beta", _p), ("ln_sel", _p),
+        ("ln_stride", _i), ("rows_per_batch", _i),
+        ("epi_scale", _p), ("epi_shift", _p), ("bvec", _p), ("act", _i), ("residual", _p),
+        ("out", _p), ("oD", _i), ("oH", _i), ("oW", _i), ("osd", _i), ("osh", _i), ("osw", _i),
+        ("ood", _i), ("ooh", _i), ("oow", _i), ("out_pitch", _i), ("out_mode", _i),
+    ]
+
+
+class StepDesc(C.Structure):
+    _fields_ = [
+        ("logits_c", _p), ("logits_u", _p), ("tok_in", _p), ("tok_out", _p),
+        ("B", _i), ("L", _i), ("K", _i), ("T", _i), ("guidance", C.c_float),
+        ("sched", _p * 8), ("t_dev", _p), ("seed", C.c_uint64), ("stream_dev", _p), ("row0", _i64),
+        ("post_dbg", _p), ("x0_dbg", _p),
+    ]
+
+
+class GsddError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises loudly if it has not been built (./build.sh or __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GsddError(f"{LIB_PATH} is missing: the HIP extension must be built (./build.sh); "
+                            "there is no CPU fallback for this path")
+        L = C.CDLL(LIB_PATH)
+        L.gsdd_last_error.restype = C.c_char_p
+        L.gsdd_gemm.argtypes = [C.POINTER(GemmDesc), _p]
+        L.gsdd_row_stats.argtypes = [_p, _i64, _i, C.c_float, _p, _p]
+        L.gsdd_ncdhw_to_rows.argtypes = [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]
+        L.gsdd_axial_attention.argtypes = [_p, _i, _i, _i, _i, _i, _i, _p, _p]
+        L.gsdd_nearest_code.argtypes = [_p, _i64, _i, _p, _i, _p, _p, _p]
+        L.gsdd_d3pm_embed.argtypes = [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p]
+        L.gsdd_adaln_table.argtypes = [_p, _i, _i, _p, _p, _p, _p]
+        L.gsdd_small_linear.argtypes = [_p, _i, _i, _p, _p, _i, _p, _p]
+        L.gsdd_d3pm_attention.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p]
+        L.gsdd_d3pm_cross_attention.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p]
+        L.gsdd_d3pm_step.argtypes = [C.POINTER(StepDesc), _p]
+        L.gsdd_d3pm_q_sample.argtypes = [_p, _p, _i, _i, _i, _i, C.POINTER(_p), _p, C.c_uint64, _p, _i64, _p]
+        L.gsdd_advance.argtypes = [_p, _i, _i64, _p, _i64, _p]
+        L.gsdd_philox_uniform.argtypes = [C.c_uint64, _i64, _i64, _i64, _i, _p, _p]
+        L.gsdd_graph_begin.argtypes = [_p]
+        L.gsdd_graph_end.argtypes = [_p, C.POINTER(_p)]
+        L.gsdd_graph_launch.argtypes = [_p, _p]
+        L.gsdd_graph_destroy.argtypes = [_p]
+        L.gsdd_event_create.argtypes = [C.POINTER(_p)]
+        L.gsdd_event_record.argtypes = [_p, _p]
+        L.gsdd_event_elapsed_ms.argtypes = [_p, _p, C.POINTER(C.c_float)]
+        L.gsdd_event_destroy.argtypes = [_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GsddError(f"gsdd error {rc}: {lib().gsdd_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must live on the GPU and be contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GsddError("the HIP path needs tensors on a ROCm device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise GsddError("non-contiguous tensor handed to the C ABI")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)

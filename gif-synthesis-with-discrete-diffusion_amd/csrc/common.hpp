@@ -1,0 +1,76 @@
+// Shared helpers for the gfx950 kernels (host error plumbing, wave64 reductions, Philox).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/gsdd.h"
+
+namespace gsdd {
+
+void set_error(const std::string& s);
+
+#define GSDD_CHECK_ARG(cond, msg)                                                      \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            ::gsdd::set_error(std::string(__func__) + ": " + (msg) + " [" #cond "]"); \
+            return GSDD_E_ARG;                                                         \
+        }                                                                              \
+    } while (0)
+
+#define GSDD_CHECK_HIP(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            ::gsdd::set_error(std::string(__func__) + ": " #expr " -> " + hipGetErrorString(e_)); \
+            return GSDD_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define GSDD_CHECK_LAUNCH() GSDD_CHECK_HIP(hipGetLastError())
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------- wave64 reductions (all lanes get the result)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (same stream as oracle/philox.py)
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// uniforms for 4 consecutive columns (col4*4 .. col4*4+3) of row `row` in a draw whose rows hold kp4 quads
+__device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint32_t stream_id, uint64_t row, uint32_t kp4,
+                                                  uint32_t col4) {
+    const uint64_t ctr = row * (uint64_t)kp4 + col4;
+    const uint4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), stream_id, 0u, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+    constexpr float S = 1.0f / 16777216.0f;
+    return make_float4((float)(r.x >> 8) * S, (float)(r.y >> 8) * S, (float)(r.z >> 8) * S, (float)(r.w >> 8) * S);
+}
+
+}  // namespace gsdd

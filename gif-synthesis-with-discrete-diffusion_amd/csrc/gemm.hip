@@ -1,0 +1,314 @@
+// Generic fp32 implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, gfx950).
+//
+//   out[orow(m)][n] = epi( sum_{tap} sum_{c<Cin} pro(in[src(m,tap)][c]) * w[tap][n][c] )
+//
+// Block tile 128 x BN x 32, 256 threads = 4 waves (2x2), each wave 64 x BN/2 as 32x32 MFMA tiles.
+// Both operands are staged through LDS "index-major, k-contiguous" ([row][32+4 pad]); MFMA step s of
+// lane half h consumes memory k = 16h + s for A and B alike, so one ds_read_b128 feeds 4 MFMA steps
+// and the padded pitch (36 dwords) is conflict-free for the b128 lane groups.  Double-buffered LDS,
+// next chunk's global loads are issued before the current chunk's 16 MFMA steps.
+//
+// Replaces (see include/gsdd.h): nn.Conv3d / nn.ConvTranspose3d (videogpt_vq_vae.py:289-332),
+// nn.Linear (model_utils.py:223-233, transformer_utils.py:36-43,258-263,353-356), BatchNorm(eval)+ReLU
+// folded as pro/epilogue (videogpt_vq_vae.py:125-133), LayerNorm apply (transformer_utils.py:157,217,354).
+#include "common.hpp"
+
+namespace gsdd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BK = 32, LDP = 36;
+
+template <int BN>
+struct GemmSmem {
+    float a[2][BM][LDP];
+    float b[2][BN][LDP];
+};
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v * (1.f / (1.f + expf(-1.702f * v)));   // x * sigmoid(1.702 x)
+    return v;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, const int64_t M) {
+    constexpr int NT = BN / 64;          // 32-wide n tiles per wave
+    constexpr int BJ = BN / 32;          // weight rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    GemmSmem<BN>& sm = *reinterpret_cast<GemmSmem<BN>*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t bm0 = (int64_t)blockIdx.x * BM;
+    const int bn0 = blockIdx.y * BN;
+    const int kq = tid & 7, r0 = tid >> 3;
+
+    // ---- per-thread staged rows of the activation operand
+    int ti0[4], hi0[4], wi0[4];
+    int64_t nb[4];
+    bool rvalid[4];
+    float mu[4], rs[4];
+    int64_t sel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = bm0 + r0 + 32 * j;
+        rvalid[j] = m < M;
+        const int64_t mm = rvalid[j] ? m : 0;
+        if (d.gather != nullptr) {
+            nb[j] = rvalid[j] ? d.gather[mm] : 0;
+            ti0[j] = hi0[j] = wi0[j] = 0;
+        } else {
+            int64_t q = mm;
+            const int wo = (int)(q % d.Wo); q /= d.Wo;
+            const int ho = (int)(q % d.Ho); q /= d.Ho;
+            const int to = (int)(q % d.Do); q /= d.Do;
+            nb[j] = q;
+            ti0[j] = to * d.sd; hi0[j] = ho * d.sh; wi0[j] = wo * d.sw;
+        }
+        mu[j] = 0.f; rs[j] = 1.f; sel[j] = 0;
+        if (d.ln_stats != nullptr) {
+            mu[j] = d.ln_stats[2 * mm]; rs[j] = d.ln_stats[2 * mm + 1];
+            if (d.ln_sel != nullptr) sel[j] = d.ln_sel[mm / d.rows_per_batch];
+        }
+    }
+
+    const int cchunks = (d.Cin + BK - 1) / BK;
+    const int nchunks = d.ntaps * cchunks;
+
+    float4 ra[4], rb[BJ];
+    auto load_chunk = [&](int chunk) {
+        const int tap = chunk / cchunks;
+        const int c = (chunk - tap * cchunks) * BK + 4 * kq;
+        const bool cvalid = c < d.Cin;
+        int dt = 0, dh = 0, dw = 0;
+        if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
+        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.pro_scale != nullptr && cvalid) {
+            ps = *reinterpret_cast<const float4*>(d.pro_scale + c);
+            pb = *reinterpret_cast<const float4*>(d.pro_shift + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = rvalid[j] && cvalid;
+            int64_t row;
+            if (d.gather != nullptr) {
+                row = nb[j];
+            } else {
+                const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
+                ok = ok && (unsigned)ti < (unsigned)d.Di && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+                row = ((nb[j] * d.Di + ti) * d.Hi + hi) * (int64_t)d.Wi + wi;
+            }
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(d.in + row * d.in_pitch + c);
+                if (d.pro_scale != nullptr) {
+                    v.x = fmaxf(fmaf(v.x, ps.x, pb.x), 0.f); v.y = fmaxf(fmaf(v.y, ps.y, pb.y), 0.f);
+                    v.z = fmaxf(fmaf(v.z, ps.z, pb.z), 0.f); v.w = fmaxf(fmaf(v.w, ps.w, pb.w), 0.f);
+                }
+                if (d.ln_stats != nullptr) {
+                    const float4 g = *reinterpret_cast<const float4*>(d.ln_gamma + sel[j] * d.ln_stride + c);
+                    const float4 bt = *reinterpret_cast<const float4*>(d.ln_beta + sel[j] * d.ln_stride + c);
+                    v.x = (v.x - mu[j]) * rs[j] * g.x + bt.x; v.y = (v.y - mu[j]) * rs[j] * g.y + bt.y;
+                    v.z = (v.z - mu[j]) * rs[j] * g.z + bt.z; v.w = (v.w - mu[j]) * rs[j] * g.w + bt.w;
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int n = bn0 + r0 + 32 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < d.Cout && cvalid) v = *reinterpret_cast<const float4*>(d.w + ((int64_t)tap * d.Cout + n) * d.Cin + c);
+            rb[j] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = rb[j];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 af[2], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                af[mt] = *reinterpret_cast<const float4*>(&sm.a[buf][wm * 64 + mt * 32 + li][16 * lh + 4 * q]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bf[nt] = *reinterpret_cast<const float4*>(&sm.b[buf][wn * (BN / 2) + nt * 32 + li][16 * lh + 4 * q]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].x, bf[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].y, bf[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].z, bf[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].w, bf[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+        if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column n = li, rows (r&3)+8*(r>>2)+4*lh of each 32x32 tile
+    const bool linear_rows = (d.oD == d.Do && d.oH == d.Ho && d.oW == d.Wo && d.osd == 1 && d.osh == 1 && d.osw == 1 &&
+                              d.ood == 0 && d.ooh == 0 && d.oow == 0);
+    const int64_t ohw = (int64_t)d.oH * d.oW;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = bn0 + wn * (BN / 2) + nt * 32 + li;
+        const bool nok = n < d.Cout;
+        const float es = (d.epi_scale != nullptr && nok) ? d.epi_scale[n] : 1.f;
+        const float eh = (d.epi_shift != nullptr && nok) ? d.epi_shift[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = bm0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= M || !nok) continue;
+                float v = acc[mt][nt][r];
+                if (d.epi_scale != nullptr) v *= es;
+                v += eh;
+                if (d.bvec != nullptr) v += d.bvec[(m / d.rows_per_batch) * d.Cout + n];
+                v = act_fn(v, d.act);
+                int64_t addr;
+                if (d.out_mode == 2) {
+                    addr = ((int64_t)(n >> 2) * M + m) * 4 + (n & 3);
+                } else {
+                    int64_t orow = m, bidx = 0, od = 0, rem = 0;
+                    if (!linear_rows || d.out_mode == 1) {
+                        int64_t q = m;
+                        const int wo = (int)(q % d.Wo); q /= d.Wo;
+                        const int ho = (int)(q % d.Ho); q /= d.Ho;
+                        const int to = (int)(q % d.Do); q /= d.Do;
+                        bidx = q;
+                        od = (int64_t)to * d.osd + d.ood;
+                        rem = (int64_t)(ho * d.osh + d.ooh) * d.oW + (wo * d.osw + d.oow);
+                        orow = (bidx * d.oD + od) * ohw + rem;
+                    }
+                    if (d.out_mode == 1) addr = ((bidx * d.Cout + n) * d.oD + od) * ohw + rem;
+                    else addr = orow * d.out_pitch + n;
+                }
+                if (d.residual != nullptr) v += d.residual[addr];
+                d.out[addr] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* x, int64_t M, int C, float eps, float* stats) {
+    // 16 lanes per row (float4 each per pass); two-pass mean / biased variance like nn.LayerNorm
+    const int lane16 = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool ok = row < M;
+    const float* p = x + (ok ? row : 0) * C;
+    float s = 0.f;
+    for (int c = 4 * lane16; c < C; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = 4 * lane16; c < C; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, dd = v.w - mean;
+        q += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (ok && lane16 == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = 1.0f / sqrtf(q / (float)C + eps);
+    }
+}
+
+__global__ void ncdhw_to_rows_kernel(const float* x, int N, int C, int D, int H, int W, int Cpad, int padw, float* out) {
+    // out[n][d][h][w + padw][Cpad], zero-filled pad columns / channels
+    const int Wp = W + 2 * padw;
+    const int64_t total = (int64_t)N * D * H * Wp;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t q = i;
+    const int wp = (int)(q % Wp); q /= Wp;
+    const int h = (int)(q % H); q /= H;
+    const int dd = (int)(q % D); q /= D;
+    const int64_t n = q;
+    const int w = wp - padw;
+    for (int c = 0; c < Cpad; ++c) {
+        float v = 0.f;
+        if (c < C && w >= 0 && w < W) v = x[(((n * C + c) * D + dd) * H + h) * (int64_t)W + w];
+        out[i * Cpad + c] = v;
+    }
+}
+
+}  // namespace gsdd
+
+using namespace gsdd;
+
+extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
+    GSDD_CHECK_ARG(d != nullptr, "null descriptor");
+    GSDD_CHECK_ARG(d->in && d->w && d->out, "null tensor pointer");
+    GSDD_CHECK_ARG(d->N > 0 && d->Do > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "bad sizes");
+    GSDD_CHECK_ARG(d->Cin % 4 == 0 && d->in_pitch % 4 == 0, "Cin and in_pitch must be multiples of 4");
+    GSDD_CHECK_ARG(d->ntaps >= 1 && (d->ntaps == 1 || d->taps != nullptr), "taps table required");
+    GSDD_CHECK_ARG(d->gather == nullptr || d->ntaps == 1, "gather needs ntaps == 1");
+    GSDD_CHECK_ARG((d->pro_scale == nullptr) == (d->pro_shift == nullptr), "pro_scale/pro_shift come together");
+    GSDD_CHECK_ARG(d->ln_stats == nullptr || (d->ln_gamma && d->ln_beta && d->ntaps == 1 && d->gather == nullptr),
+                   "LayerNorm prologue needs gamma/beta and a plain row operand");
+    GSDD_CHECK_ARG((d->ln_sel == nullptr && d->bvec == nullptr) || d->rows_per_batch > 0, "rows_per_batch required");
+    GSDD_CHECK_ARG(d->out_mode >= 0 && d->out_mode <= 2, "bad out_mode");
+    GSDD_CHECK_ARG(d->gather != nullptr || (d->Di > 0 && d->Hi > 0 && d->Wi > 0), "bad input dims");
+    GSDD_CHECK_ARG(d->out_mode == 2 || (d->oD > 0 && d->oH > 0 && d->oW > 0), "bad output dims");
+    GSDD_CHECK_ARG(d->out_mode != 0 || d->out_pitch >= d->Cout, "out_pitch too small");
+    const int64_t M = (int64_t)d->N * d->Do * d->Ho * d->Wo;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((M + BM - 1) / BM);
+    if (d->Cout > 64) {
+        const dim3 grid(gx, (d->Cout + 127) / 128);
+        hipLaunchKernelGGL(gemm_kernel<128>, grid, dim3(256), sizeof(GemmSmem<128>), st, *d, M);
+    } else {
+        const dim3 grid(gx, 1);
+        hipLaunchKernelGGL(gemm_kernel<64>, grid, dim3(256), sizeof(GemmSmem<64>), st, *d, M);
+    }
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_row_stats(const float* x, int64_t M, int C, float eps, float* stats, void* stream) {
+    GSDD_CHECK_ARG(x && stats && M > 0 && C > 0 && C % 4 == 0, "bad args");
+    const int64_t threads = M * 16;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       M, C, eps, stats);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_ncdhw_to_rows(const float* x, int N, int C, int D, int H, int W, int Cpad, int padw, float* out,
+                                  void* stream) {
+    GSDD_CHECK_ARG(x && out && N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && Cpad >= C && padw >= 0, "bad args");
+    const int64_t total = (int64_t)N * D * H * (W + 2 * padw);
+    hipLaunchKernelGGL(ncdhw_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, N, C, D, H, W, Cpad, padw, out);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}

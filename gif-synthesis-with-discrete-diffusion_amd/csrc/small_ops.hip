@@ -1,0 +1,265 @@
+// Small / memory-bound operators of the path: token+position embedding, AdaLayerNorm table,
+// tiny linears for the condition token, axial attention of the VQ-VAE res blocks, nearest-code search.
+#include "common.hpp"
+
+namespace gsdd {
+
+// ------------------------------------------------------------------ DalleMaskImageEmbedding (dalle_mask_image_embedding.py:59-79)
+__global__ void embed_kernel(const int64_t* tok, int64_t rows, int L, int D, const float* emb, int n_embed,
+                             const float* pos, int rep, float* x) {
+    const int q4 = D >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * q4) return;
+    const int64_t row = i / q4;
+    const int c = (int)(i % q4) * 4;
+    int64_t t = tok[row];
+    t = t < 0 ? 0 : t;                                   // index[index < 0] = 0  (:63)
+    t = t >= n_embed ? n_embed - 1 : t;                  // the reference raises; never index out of bounds here
+    const int l = (int)(row % L);
+    const float4 e = *reinterpret_cast<const float4*>(emb + t * D + c);
+    const float4 p = *reinterpret_cast<const float4*>(pos + (int64_t)l * D + c);
+    const float4 o = make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w);
+    for (int r = 0; r < rep; ++r) *reinterpret_cast<float4*>(x + ((int64_t)r * rows + row) * D + c) = o;
+}
+
+// ------------------------------------------------------------------ AdaLayerNorm table (transformer_utils.py:138-159)
+__global__ void adaln_table_kernel(const float* emb, int T, int D, const float* w, const float* bias, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * 2 * D) return;
+    const int t = i / (2 * D), j = i % (2 * D);
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) {
+        const float e = emb[t * D + k];
+        const float si = e / (1.f + expf(-e));            // SiLU
+        s = fmaf(si, w[j * D + k], s);
+    }
+    s += bias[j];
+    out[i] = j < D ? 1.f + s : s;                          // (1 + scale) | shift
+}
+
+__global__ void small_linear_kernel(const float* x, int R, int Cin, const float* w, const float* b, int Cout, float* y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * Cout) return;
+    const int r = i / Cout, j = i % Cout;
+    float s = 0.f;
+    for (int k = 0; k < Cin; ++k) s = fmaf(x[(int64_t)r * Cin + k], w[(int64_t)j * Cin + k], s);
+    y[i] = s + (b != nullptr ? b[j] : 0.f);
+}
+
+// ------------------------------------------------------------------ axial attention (model_utils.py:318-337, :586-600)
+// One wave per (line, head, axis).  S = axis length (<= 64), d = C / n_head.
+__global__ __launch_bounds__(64) void axial_attention_kernel(const float* qkv, int N, int T, int H, int W, int C, int n_head,
+                                                             int axis /* 0: w, 1: h, 2: t */, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int head = blockIdx.y;
+    const int d = C / n_head;
+    const int S = axis == 0 ? W : (axis == 1 ? H : T);
+    int64_t line = blockIdx.x;                            // enumerates the other two dims and n
+    // position stride along the axis and line base position
+    int64_t stride, basepos;
+    if (axis == 0) { stride = 1; basepos = line * W; }                                        // line = (n,t,h)
+    else if (axis == 1) { stride = W; const int64_t w = line % W; const int64_t nt = line / W; basepos = nt * H * W + w; }
+    else { stride = (int64_t)H * W; const int64_t hw = line % ((int64_t)H * W); const int64_t n = line / ((int64_t)H * W);
+           basepos = n * T * H * W + hw; }
+    float* sq = smf;                  // [S][d+1]
+    float* sk = sq + S * (d + 1);
+    float* sv = sk + S * (d + 1);
+    float* sp = sv + S * (d + 1);     // [S][S]
+    const int lane = threadIdx.x;
+    const int64_t rowpitch = 9 * (int64_t)C;
+    const int64_t colbase = (int64_t)axis * 3 * C + head * d;
+    for (int i = lane; i < S * d; i += 64) {
+        const int s = i / d, e = i % d;
+        const float* row = qkv + (basepos + s * stride) * rowpitch + colbase + e;
+        sq[s * (d + 1) + e] = row[0];
+        sk[s * (d + 1) + e] = row[C];
+        sv[s * (d + 1) + e] = row[2 * C];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)d);
+    for (int i = lane; i < S * S; i += 64) {
+        const int a = i / S, bb = i % S;
+        float s = 0.f;
+        for (int e = 0; e < d; ++e) s = fmaf(sq[a * (d + 1) + e], sk[bb * (d + 1) + e], s);
+        sp[i] = s * scale;            // attn / sqrt(d)  (:591)
+    }
+    __syncthreads();
+    for (int a = lane; a < S; a += 64) {                  // softmax rows
+        float mx = -INFINITY;
+        for (int j = 0; j < S; ++j) mx = fmaxf(mx, sp[a * S + j]);
+        float l = 0.f;
+        for (int j = 0; j < S; ++j) { const float p = expf(sp[a * S + j] - mx); sp[a * S + j] = p; l += p; }
+        const float inv = 1.f / l;
+        for (int j = 0; j < S; ++j) sp[a * S + j] *= inv;
+    }
+    __syncthreads();
+    for (int i = lane; i < S * d; i += 64) {
+        const int a = i / d, e = i % d;
+        float o = 0.f;
+        for (int j = 0; j < S; ++j) o = fmaf(sp[a * S + j], sv[j * (d + 1) + e], o);
+        out[(basepos + a * stride) * (3 * (int64_t)C) + (int64_t)axis * C + head * d + e] = o;
+    }
+}
+
+// ------------------------------------------------------------------ nearest code (videogpt_vq_vae.py:178-183)
+// 64 z rows x 64 codes per tile, 256 threads, 4x4 register micro-tile; running per-thread arg-min, one
+// 16-lane reduction at the end.  d = (|z|^2 - 2 z.e) + |e|^2 exactly in that association; first minimum wins.
+constexpr int NC_T = 64;
+__global__ __launch_bounds__(256) void nearest_code_kernel(const float* z, int64_t M, int E, const float* cb, int K,
+                                                           int64_t* idx, float* zq) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int EP = E + 4;
+    float* sz = smf;                   // [64][EP]
+    float* sc = sz + NC_T * EP;        // [64][EP]
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * NC_T;
+    for (int i = tid; i < NC_T * (E >> 2); i += 256) {
+        const int r = i / (E >> 2), c = (i % (E >> 2)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + r < M) v = *reinterpret_cast<const float4*>(z + (m0 + r) * E + c);
+        *reinterpret_cast<float4*>(&sz[r * EP + c]) = v;
+    }
+    __syncthreads();
+    float zn[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) { const float t = sz[(ty * 4 + a) * EP + e]; s += t * t; }
+        zn[a] = s;
+    }
+    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int bidx[4] = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < K; k0 += NC_T) {
+        __syncthreads();
+        for (int i = tid; i < NC_T * (E >> 2); i += 256) {
+            const int r = i / (E >> 2), c = (i % (E >> 2)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + r < K) v = *reinterpret_cast<const float4*>(cb + (int64_t)(k0 + r) * E + c);
+            *reinterpret_cast<float4*>(&sc[r * EP + c]) = v;
+        }
+        __syncthreads();
+        float dot[4][4], en[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot[a][c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) en[c] = 0.f;
+        for (int e = 0; e < E; e += 4) {
+            float4 zr[4], cr[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) zr[a] = *reinterpret_cast<const float4*>(&sz[(ty * 4 + a) * EP + e]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cr[c] = *reinterpret_cast<const float4*>(&sc[(tx + 16 * c) * EP + e]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                en[c] += cr[c].x * cr[c].x; en[c] += cr[c].y * cr[c].y; en[c] += cr[c].z * cr[c].z; en[c] += cr[c].w * cr[c].w;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    dot[a][c] = fmaf(zr[a].x, cr[c].x, dot[a][c]); dot[a][c] = fmaf(zr[a].y, cr[c].y, dot[a][c]);
+                    dot[a][c] = fmaf(zr[a].z, cr[c].z, dot[a][c]); dot[a][c] = fmaf(zr[a].w, cr[c].w, dot[a][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                     // codes tx + 16c: increasing index inside a thread
+            const int code = k0 + tx + 16 * c;
+            if (code < K) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float dd = (zn[a] - 2.f * dot[a][c]) + en[c];
+                    if (dd < best[a]) { best[a] = dd; bidx[a] = code; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float v = best[a];
+        int bi = bidx[a];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov < v || (ov == v && oi < bi)) { v = ov; bi = oi; }
+        }
+        bidx[a] = bi;
+        const int64_t m = m0 + ty * 4 + a;
+        if (tx == 0 && m < M) idx[m] = bi;
+    }
+    if (zq != nullptr) {                                  // F.embedding(encoding_indices, embeddings)  (:186)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int64_t m = m0 + ty * 4 + a;
+            if (m < M)
+                for (int e = tx * 4; e < E; e += 64)
+                    *reinterpret_cast<float4*>(zq + m * E + e) = *reinterpret_cast<const float4*>(cb + (int64_t)bidx[a] * E + e);
+        }
+    }
+}
+
+}  // namespace gsdd
+
+using namespace gsdd;
+
+extern "C" int gsdd_d3pm_embed(const int64_t* tok, int B, int L, int D, const float* emb, int n_embed, const float* pos,
+                               int rep, float* x, void* stream) {
+    GSDD_CHECK_ARG(tok && emb && pos && x, "null pointer");
+    GSDD_CHECK_ARG(B > 0 && L > 0 && D > 0 && D % 4 == 0 && n_embed > 0 && rep >= 1, "bad sizes");
+    const int64_t rows = (int64_t)B * L, n = rows * (D / 4);
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tok, rows, L, D,
+                       emb, n_embed, pos, rep, x);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_adaln_table(const float* emb, int T, int D, const float* lin_w, const float* lin_b, float* out,
+                                void* stream) {
+    GSDD_CHECK_ARG(emb && lin_w && lin_b && out && T > 0 && D > 0, "bad args");
+    const int n = T * 2 * D;
+    hipLaunchKernelGGL(adaln_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, emb, T, D, lin_w,
+                       lin_b, out);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const float* b, int Cout, float* y,
+                                 void* stream) {
+    GSDD_CHECK_ARG(x && w && y && R > 0 && Cin > 0 && Cout > 0, "bad args");
+    const int n = R * Cout;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, R, Cin, w, b, Cout,
+                       y);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W, int C, int n_head, float* out,
+                                    void* stream) {
+    GSDD_CHECK_ARG(qkv && out, "null pointer");
+    GSDD_CHECK_ARG(N > 0 && T > 0 && H > 0 && W > 0 && C > 0 && n_head > 0 && C % n_head == 0, "bad sizes");
+    GSDD_CHECK_ARG(T <= 64 && H <= 64 && W <= 64, "axis length > 64 unsupported");
+    const int d = C / n_head;
+    hipStream_t st = (hipStream_t)stream;
+    const int axes_len[3] = {W, H, T};
+    const int64_t pos = (int64_t)N * T * H * W;
+    for (int axis = 0; axis < 3; ++axis) {
+        const int S = axes_len[axis];
+        const size_t lds = (size_t)(3 * S * (d + 1) + S * S) * sizeof(float);
+        GSDD_CHECK_ARG(lds <= 64 * 1024, "line does not fit LDS");
+        hipLaunchKernelGGL(axial_attention_kernel, dim3((unsigned)(pos / S), n_head, 1), dim3(64), lds, st, qkv, N, T, H, W,
+                           C, n_head, axis, out);
+        GSDD_CHECK_LAUNCH();
+    }
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K, int64_t* idx, float* zq,
+                                 void* stream) {
+    GSDD_CHECK_ARG(z && cb && idx, "null pointer");
+    GSDD_CHECK_ARG(M > 0 && K > 0 && E > 0 && E % 4 == 0 && E <= 256, "E must be a multiple of 4, <= 256");
+    const size_t lds = (size_t)2 * NC_T * (E + 4) * sizeof(float);
+    hipLaunchKernelGGL(nearest_code_kernel, dim3((unsigned)((M + NC_T - 1) / NC_T)), dim3(256), lds, (hipStream_t)stream, z,
+                       M, E, cb, K, idx, zq);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}

@@ -1,0 +1,416 @@
+"""D3PM denoiser + discrete-diffusion shells with the reference's constructors, method names and
+state_dict keys, computing on gfx950 through the C ABI.
+
+Reference: src/models/motionencoder/{dalle_mask_image_embedding,transformer_utils,diffusion_transformer}.py and
+src/models/networks/discrete_diffusion.py.  The nn.Module tree only owns parameters under the
+reference's names; the sampling loop runs as one captured hipGraph per reverse
+step, replayed diffusion_step times with the timestep and the Philox stream id living in device memory.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import GsddError
+
+
+# ----------------------------------------------------------------------------- parameter containers
+class DalleMaskImageEmbedding(nn.Module):
+    """dalle_mask_image_embedding.py:27-57 (num_embed+1 rows, last = [MASK])."""
+
+    def __init__(self, num_embed=8192, spatial_size=[32, 32], embed_dim=3968, trainable=True,
+                 pos_emb_type="embedding"):
+        super().__init__()
+        if isinstance(spatial_size, int):
+            spatial_size = [spatial_size, spatial_size]
+        if pos_emb_type != "embedding":
+            raise NotImplementedError("only pos_emb_type='embedding' is used by the reference configs")
+        self.spatial_size = list(spatial_size)
+        self.num_embed = num_embed + 1
+        self.embed_dim = embed_dim
+        self.trainable = trainable
+        self.pos_emb_type = pos_emb_type
+        self.emb = nn.Embedding(self.num_embed, embed_dim)
+        self.height_emb = nn.Embedding(self.spatial_size[0], embed_dim)
+        self.width_emb = nn.Embedding(self.spatial_size[1], embed_dim)
+        if not trainable:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def pos_table(self, L):
+        """(height_emb[p // W] + width_emb[p % W])[:L]  (dalle_mask_image_embedding.py:70-77)"""
+        Hs, Ws = self.spatial_size
+        if Hs * Ws < L:
+            raise GsddError(f"spatial_size {self.spatial_size} has fewer than content_seq_len={L} positions")
+        pos = (self.height_emb.weight.unsqueeze(1) + self.width_emb.weight.unsqueeze(0)).view(Hs * Ws, -1)
+        return pos[:L].contiguous()
+
+
+class AdaLayerNorm(nn.Module):
+    """transformer_utils.py:138-149 (timestep_type='adalayernorm' -> nn.Embedding)."""
+
+    def __init__(self, n_embd, diffusion_step, emb_type="adalayernorm"):
+        super().__init__()
+        if "abs" in emb_type:
+            raise NotImplementedError("sinusoidal timestep embedding is not used by the reference configs")
+        self.emb = nn.Embedding(diffusion_step, n_embd)
+        self.linear = nn.Linear(n_embd, n_embd * 2)
+        self.diff_step = diffusion_step
+
+
+class _Attention(nn.Module):
+    def __init__(self, n_embd, kv_dim):
+        super().__init__()
+        self.key = nn.Linear(kv_dim, n_embd)
+        self.query = nn.Linear(n_embd, n_embd)
+        self.value = nn.Linear(kv_dim, n_embd)
+        self.proj = nn.Linear(n_embd, n_embd)
+
+
+class Block(nn.Module):
+    """transformer_utils.py:178-264, attn_type='selfcross'."""
+
+    def __init__(self, n_embd, n_head, condition_dim, diffusion_step, timestep_type, mlp_hidden_times):
+        super().__init__()
+        self.ln1 = AdaLayerNorm(n_embd, diffusion_step, timestep_type)
+        self.ln2 = nn.LayerNorm(n_embd)
+        self.attn1 = _Attention(n_embd, n_embd)
+        self.attn2 = _Attention(n_embd, condition_dim)
+        self.ln1_1 = AdaLayerNorm(n_embd, diffusion_step, timestep_type)
+        self.mlp = nn.Sequential(nn.Linear(n_embd, mlp_hidden_times * n_embd), nn.Identity(),
+                                 nn.Linear(mlp_hidden_times * n_embd, n_embd), nn.Identity())
+
+
+class Text2ImageTransformer(nn.Module):
+    """Drop-in for transformer_utils.py:299-444.  forward(input, cond_emb, t) -> logits (B, K, L)."""
+
+    def __init__(self, dalle, condition_seq_len=77, n_layer=14, n_embd=1024, n_head=16, content_seq_len=1024,
+                 attn_pdrop=0, resid_pdrop=0, mlp_hidden_times=4, block_activate=None, attn_type="selfcross",
+                 content_spatial_size=[32, 32], condition_dim=512, diffusion_step=1000, timestep_type="adalayernorm",
+                 mlp_type="fc", checkpoint=False):
+        super().__init__()
+        if attn_type != "selfcross" or mlp_type != "fc" or block_activate != "GELU2":
+            raise NotImplementedError("only attn_type='selfcross', mlp_type='fc', block_activate='GELU2' "
+                                      "(the reference configs) are built")
+        if n_embd % n_head != 0 or n_embd // n_head != 4:
+            raise NotImplementedError("the HIP attention kernel is specialised for head dim 4 (n_embd 64, 16 heads)")
+        if attn_pdrop != 0 or resid_pdrop != 0:
+            raise NotImplementedError("dropout > 0 is not used by the reference configs")
+        self.content_emb = dalle
+        self.n_layer, self.n_embd, self.n_head = n_layer, n_embd, n_head
+        self.blocks = nn.Sequential(*[Block(n_embd, n_head, condition_dim, diffusion_step, timestep_type,
+                                            mlp_hidden_times) for _ in range(n_layer)])
+        out_cls = self.content_emb.num_embed - 1
+        self.to_logits = nn.Sequential(nn.LayerNorm(n_embd), nn.Linear(n_embd, out_cls))
+        self.condition_seq_len, self.content_seq_len = condition_seq_len, content_seq_len
+        self.condition_dim, self.diffusion_step = condition_dim, diffusion_step
+        self.apply(self._init_weights)
+        self._packed, self._packed_key = None, None
+
+    @staticmethod
+    def _init_weights(module):                       # transformer_utils.py:363-371
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if isinstance(module, nn.Linear) and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm) and module.elementwise_affine:
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    # ------------------------------------------------------------------ packed weights
+    def packed(self):
+        key = tuple((t.data_ptr(), t._version) for t in self.parameters())
+        if self._packed is None or key != self._packed_key:
+            with torch.no_grad():
+                self._packed = self._pack()
+            self._packed_key = key
+        return self._packed
+
+    def _pack(self):
+        p = {"pos": self.content_emb.pos_table(self.content_seq_len), "emb": self.content_emb.emb.weight.contiguous(),
+             "layers": []}
+        for blk in self.blocks:
+            a1, a2 = blk.attn1, blk.attn2
+            lay = dict(
+                ada1=ops.adaln_table(blk.ln1.emb.weight.contiguous(), blk.ln1.linear.weight.contiguous(),
+                                     blk.ln1.linear.bias.contiguous()),
+                ada2=ops.adaln_table(blk.ln1_1.emb.weight.contiguous(), blk.ln1_1.linear.weight.contiguous(),
+                                     blk.ln1_1.linear.bias.contiguous()),
+                wqkv=torch.cat([a1.query.weight, a1.key.weight, a1.value.weight], 0).contiguous(),
+                bqkv=torch.cat([a1.query.bias, a1.key.bias, a1.value.bias], 0).contiguous(),
+                wproj=a1.proj.weight.contiguous(), bproj=a1.proj.bias.contiguous(),
+                wq2=a2.query.weight.contiguous(), bq2=a2.query.bias.contiguous(),
+                wk2=a2.key.weight.contiguous(), bk2=a2.key.bias.contiguous(),
+                wv2=a2.value.weight.contiguous(), bv2=a2.value.bias.contiguous(),
+                wproj2=a2.proj.weight.contiguous(), bproj2=a2.proj.bias.contiguous(),
+                g2=blk.ln2.weight.contiguous(), b2=blk.ln2.bias.contiguous(),
+                w1=blk.mlp[0].weight.contiguous(), bb1=blk.mlp[0].bias.contiguous(),
+                w2=blk.mlp[2].weight.contiguous(), bb2=blk.mlp[2].bias.contiguous())
+            p["layers"].append(lay)
+        p["gf"], p["bf"] = self.to_logits[0].weight.contiguous(), self.to_logits[0].bias.contiguous()
+        p["wl"], p["bl"] = self.to_logits[1].weight.contiguous(), self.to_logits[1].bias.contiguous()
+        return p
+
+    # ------------------------------------------------------------------ one denoiser pass on the HIP path
+    def cond_vectors(self, cond):
+        """Per-layer cross-attention operands of the condition tokens (B2, Te, cond_dim).
+        Te == 1: softmax over one key is exactly 1, so attn2 adds proj(value(cond)) to every position
+        (transformer_utils.py:95-113) -> [n_layer] tensors (B2, D).  Te > 1: (keys, values) rows."""
+        p = self.packed()
+        B2, Te, cd = cond.shape
+        flat = cond.reshape(B2 * Te, cd).contiguous().float()
+        out = []
+        for lay in p["layers"]:
+            v = ops.small_linear(flat, lay["wv2"], lay["bv2"])
+            if Te == 1:
+                out.append(ops.small_linear(v, lay["wproj2"], lay["bproj2"]))
+            else:
+                out.append((ops.small_linear(flat, lay["wk2"], lay["bk2"]), v))
+        return out
+
+    def run(self, tok, condv, Te, t2, ws, rep=1, stream=None):
+        """tok (B,L) int64; the pass runs on `rep` stacked copies of the batch (B2 = rep*B rows of cond).
+        t2: int64 [B2] timesteps on device.  ws: workspace dict from `workspace()`.  -> logits [B2*L][K]."""
+        p = self.packed()
+        B, L = tok.shape
+        B2, D, H = rep * B, self.n_embd, self.n_head
+        M = B2 * L
+        x, stats, qkv, y, hbuf, logits = ws["x"], ws["stats"], ws["qkv"], ws["y"], ws["h"], ws["logits"]
+        ops.d3pm_embed(tok, p["emb"], p["pos"], x, rep=rep, stream=stream)
+        for li, lay in enumerate(p["layers"]):
+            ops.row_stats(x, stats, stream=stream)
+            ops.linear(x, lay["wqkv"], qkv, bias=lay["bqkv"], ln=(stats, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t2, 2 * D),
+                       rows_per_batch=L, out_mode=2, stream=stream)
+            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, stream=stream)
+            if Te == 1:
+                ops.linear(y, lay["wproj"], x, bias=lay["bproj"], bvec=condv[li], rows_per_batch=L, residual=x,
+                           stream=stream)
+            else:
+                ops.linear(y, lay["wproj"], x, bias=lay["bproj"], residual=x, stream=stream)
+                ops.row_stats(x, stats, stream=stream)
+                q2 = qkv[0:H]
+                ops.linear(x, lay["wq2"], q2, bias=lay["bq2"], ln=(stats, lay["ada2"].view(-1), lay["ada2"].view(-1)[D:], t2, 2 * D),
+                           rows_per_batch=L, out_mode=2, stream=stream)
+                ops.d3pm_cross_attention(q2, condv[li][0], condv[li][1], B2, L, Te, H, y, stream=stream)
+                ops.linear(y, lay["wproj2"], x, bias=lay["bproj2"], residual=x, stream=stream)
+            ops.row_stats(x, stats, stream=stream)
+            ops.linear(x, lay["w1"], hbuf, bias=lay["bb1"], ln=(stats, lay["g2"], lay["b2"], None, 0),
+                       act=ops.ACT_GELU2, stream=stream)
+            ops.linear(hbuf, lay["w2"], x, bias=lay["bb2"], residual=x, stream=stream)
+        ops.row_stats(x, stats, stream=stream)
+        ops.linear(x, p["wl"], logits, bias=p["bl"], ln=(stats, p["gf"], p["bf"], None, 0), stream=stream)
+        return logits
+
+    def workspace(self, B2, L, device):
+        D, H = self.n_embd, self.n_head
+        M = B2 * L
+        K = self.content_emb.num_embed - 1
+        f = dict(dtype=torch.float32, device=device)
+        return {"x": torch.empty((M, D), **f), "stats": torch.empty((M, 2), **f),
+                "qkv": torch.empty((3 * H, M, 4), **f), "y": torch.empty((M, D), **f),
+                "h": torch.empty((M, self.blocks[0].mlp[0].out_features), **f),
+                "logits": torch.empty((M, K), **f)}
+
+    @torch.no_grad()
+    def forward(self, input, cond_emb, t):
+        """(B,L) int64 tokens, (B,Te,cond_dim), (B,) int64 -> logits (B, K, L) (view of [B][L][K] rows,
+        like the reference's rearrange 'b l c -> b c l', transformer_utils.py:442-443)."""
+        if not input.is_cuda:
+            raise GsddError("the denoiser runs on the HIP path only: move module and inputs to a ROCm device")
+        B, L = input.shape
+        ws = self.workspace(B, L, input.device)
+        cond_emb = cond_emb.float()
+        condv = self.cond_vectors(cond_emb)
+        logits = self.run(input.contiguous(), condv, cond_emb.shape[1], t.to(input.device).long().contiguous(), ws)
+        return logits.view(B, L, -1).transpose(1, 2)
+
+
+# ----------------------------------------------------------------------------- diffusion
+def alpha_schedule(time_step, N=100, att_1=0.99999, att_T=0.000009, ctt_1=0.000009, ctt_T=0.99999):
+    """Linear schedule in fp64 numpy (host, init only).  Reference: diffusion_transformer.py:56-69."""
+    import numpy as np
+    att = np.arange(0, time_step) / (time_step - 1) * (att_T - att_1) + att_1
+    att = np.concatenate(([1], att))
+    at = att[1:] / att[:-1]
+    ctt = np.arange(0, time_step) / (time_step - 1) * (ctt_T - ctt_1) + ctt_1
+    ctt = np.concatenate(([0], ctt))
+    one_minus_ctt = 1 - ctt
+    ct = 1 - one_minus_ctt[1:] / one_minus_ctt[:-1]
+    bt = (1 - at - ct) / N
+    att = np.concatenate((att[1:], [1]))
+    ctt = np.concatenate((ctt[1:], [0]))
+    btt = (1 - att - ctt) / N
+    return at, bt, ct, att, btt, ctt
+
+
+SCHED_ORDER = ("log_at", "log_bt", "log_ct", "log_1_min_ct", "log_cumprod_at", "log_cumprod_bt", "log_cumprod_ct",
+               "log_1_min_cumprod_ct")
+
+
+class DiffusionTransformer(nn.Module):
+    """Drop-in for diffusion_transformer.py:71-645 (sample, forward/_train_loss surface)."""
+
+    def __init__(self, *, condition_emb_config=None, transformer=None, diffusion_step=100, alpha_init_type="cos",
+                 auxiliary_loss_weight=0, adaptive_auxiliary_loss=False, mask_weight=[1, 1], learnable_cf=False,
+                 guidance_scale=5, content_seq_len=1024):
+        super().__init__()
+        if alpha_init_type != "alpha1":
+            raise ValueError("alpha_init_type must be 'alpha1' (the reference crashes on anything else, "
+                             "diffusion_transformer.py:115-118)")
+        self.condition_emb = None
+        self.transformer = transformer
+        self.content_seq_len = content_seq_len
+        self.num_classes = self.transformer.content_emb.num_embed
+        self.shape = content_seq_len
+        self.num_timesteps = diffusion_step
+        self.auxiliary_loss_weight = auxiliary_loss_weight
+        self.adaptive_auxiliary_loss = adaptive_auxiliary_loss
+        self.mask_weight = mask_weight
+        at, bt, ct, att, btt, ctt = (torch.tensor(a.astype("float64"))
+                                     for a in alpha_schedule(self.num_timesteps, N=self.num_classes - 1))
+        l1m = lambda a: torch.log(1 - a.exp() + 1e-40)
+        log_ct, log_cct = torch.log(ct), torch.log(ctt)
+        self.register_buffer("log_at", torch.log(at).float())
+        self.register_buffer("log_bt", torch.log(bt).float())
+        self.register_buffer("log_ct", log_ct.float())
+        self.register_buffer("log_cumprod_at", torch.log(att).float())
+        self.register_buffer("log_cumprod_bt", torch.log(btt).float())
+        self.register_buffer("log_cumprod_ct", log_cct.float())
+        self.register_buffer("log_1_min_ct", l1m(log_ct).float())
+        self.register_buffer("log_1_min_cumprod_ct", l1m(log_cct).float())
+        self.register_buffer("Lt_history", torch.zeros(self.num_timesteps))
+        self.register_buffer("Lt_count", torch.zeros(self.num_timesteps))
+        self.empty_text_embed = nn.Parameter(torch.randn(size=(77, 512), dtype=torch.float64))
+        self.learnable_cf = learnable_cf
+        self.guidance_scale = guidance_scale
+        self.noise_seed = 0          # Philox key; the stream id advances with every draw
+        self.noise_stream = 0
+        self.row_offset = 0          # global row of this rank's first sample (multi-GPU batch sharding)
+        self._graph_cache = {}
+
+    @property
+    def device(self):
+        return self.transformer.to_logits[-1].weight.device
+
+    def set_noise(self, seed, stream=0, row_offset=0):
+        self.noise_seed, self.noise_stream, self.row_offset = int(seed), int(stream), int(row_offset)
+
+    def _sched(self):
+        return [getattr(self, n) for n in SCHED_ORDER]
+
+    # ------------------------------------------------------------------ sampling (diffusion_transformer.py:568-644)
+    @torch.no_grad()
+    def sample(self, condition_token, condition_mask, condition_embed, cf_condition_embed, content_token=None,
+               filter_ratio=0.5, temperature=1.0, return_att_weight=False, return_logits=False, content_logits=None,
+               print_log=True, use_graph=True, trace=None, **kwargs):
+        if int(self.num_timesteps * filter_ratio) != 0:
+            raise NotImplementedError("only filter_ratio=0 (full-mask start) is used by the reference call site "
+                                      "(discrete_diffusion.py:53-60)")
+        dev = self.device
+        if dev.type != "cuda":
+            raise GsddError("sampling runs on the HIP path only: move the module to a ROCm device")
+        B = len(condition_token) if condition_token is not None else kwargs["batch_size"]
+        L, K, T = self.shape, self.num_classes - 1, self.num_timesteps
+        guided = abs(self.guidance_scale - 1) >= 1e-3
+        rep = 2 if guided else 1
+        cond = condition_embed.to(dev).float()
+        conds = torch.cat([cond, cf_condition_embed.to(dev).float().type_as(cond)], 0) if guided else cond
+        Te = conds.shape[1]
+        tr = self.transformer
+        # hipGraph capture is not allowed on the legacy default stream: the whole loop runs on a side stream
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        st = self._stream
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            condv = tr.cond_vectors(conds.contiguous())
+            ws = tr.workspace(rep * B, L, dev)
+            tok = torch.full((B, L), K, dtype=torch.int64, device=dev)                   # all [MASK] (:613-618)
+            t2 = torch.full((rep * B,), T - 1, dtype=torch.int64, device=dev)
+            sid = torch.tensor([self.noise_stream], dtype=torch.int64, device=dev)
+            sched = self._sched()
+            M = B * L
+
+            def one_step():
+                logits = tr.run(tok, condv, Te, t2, ws, rep=rep, stream=st)
+                ops.d3pm_step(logits[:M], logits[M:] if guided else None, tok, tok, sched, t2, sid, K=K, T=T,
+                              guidance=float(self.guidance_scale), seed=self.noise_seed, row0=self.row_offset * L,
+                              stream=st)
+                ops.advance(t2, -1, sid, 1, stream=st)
+
+            if use_graph and trace is None:
+                one_step()                  # eager first step (validates arguments outside capture)
+                g = ops.Graph()
+                g.begin(st)
+                one_step()                  # recorded, not executed
+                g.end(st)
+                for _ in range(T - 1):
+                    g.launch(st)
+                self._last_graph = g
+            else:
+                for _ in range(T):
+                    one_step()
+                    if trace is not None:
+                        trace.append(tok.clone())
+        torch.cuda.current_stream().wait_stream(st)
+        tok.record_stream(torch.cuda.current_stream())
+        self.noise_stream += T
+        out = {"content_token": tok}
+        if return_logits:
+            raise NotImplementedError("return_logits is unused by the reference call sites")
+        return out
+
+    # ------------------------------------------------------------------ single-step pieces (parity tests, training glue)
+    @torch.no_grad()
+    def p_sample_tokens(self, tok, cond, cf_cond, t, stream_id, post_dbg=None, x0_dbg=None):
+        """One reverse step on tokens (p_sample, diffusion_transformer.py:304-352, prior_rule 0)."""
+        dev = tok.device
+        B, L = tok.shape
+        K, T = self.num_classes - 1, self.num_timesteps
+        guided = abs(self.guidance_scale - 1) >= 1e-3
+        rep = 2 if guided else 1
+        conds = torch.cat([cond, cf_cond], 0).float().contiguous() if guided else cond.float().contiguous()
+        tr = self.transformer
+        ws = tr.workspace(rep * B, L, dev)
+        condv = tr.cond_vectors(conds)
+        t2 = torch.cat([t, t]).contiguous() if guided else t.contiguous()
+        logits = tr.run(tok.contiguous(), condv, conds.shape[1], t2.long(), ws, rep=rep)
+        sid = torch.tensor([stream_id], dtype=torch.int64, device=dev)
+        out = torch.empty_like(tok)
+        M = B * L
+        ops.d3pm_step(logits[:M], logits[M:] if guided else None, tok, out, self._sched(), t2, sid, K=K, T=T,
+                      guidance=float(self.guidance_scale), seed=self.noise_seed, row0=self.row_offset * L,
+                      post_dbg=post_dbg, x0_dbg=x0_dbg)
+        return out
+
+    def forward(self, input, return_loss=False, return_logits=True, return_att_weight=False, is_train=True, **kwargs):
+        raise NotImplementedError("D3PM training loss (_train_loss, diffusion_transformer.py:391-457) is not built "
+                                  "yet on the HIP path")
+
+
+class DiscreteDiffusion(nn.Module):
+    """Drop-in for src/models/networks/discrete_diffusion.py:8-83 (generator glue).  `textencoder` and
+    `diffusion_model` may be already-built modules or (with hydra present) configs to instantiate."""
+
+    def __init__(self, textencoder, diffusion_model, **kwargs):
+        super().__init__()
+        if not isinstance(textencoder, nn.Module) and not callable(textencoder):
+            from hydra.utils import instantiate
+            textencoder = instantiate(textencoder)
+        if not isinstance(diffusion_model, nn.Module):
+            from hydra.utils import instantiate
+            diffusion_model = instantiate(diffusion_model)
+        self.textencoder = textencoder
+        self.diffusion_model = diffusion_model
+
+    @torch.no_grad()
+    def sample_videos(self, texts, autoencoder, latent_shape=None):
+        """The inference branch of forward (discrete_diffusion.py:44-62): text -> tokens -> decoded clips."""
+        dev = autoencoder.device
+        B = len(texts)
+        text_emb = torch.zeros_like(self.textencoder(texts).unsqueeze(1).to(dev))      # (sic) :25 zeroes it
+        cf_emb = torch.zeros_like(self.textencoder([""] * B).unsqueeze(1).to(dev))      # :49
+        out = self.diffusion_model.sample(texts, None, text_emb, cf_emb, content_token=None, filter_ratio=0)
+        shape = latent_shape if latent_shape is not None else autoencoder.latent_shape
+        return autoencoder.decode(out["content_token"].view(B, *shape))

@@ -1,0 +1,202 @@
+"""Tensor-level wrappers over the C ABI (include/gsdd.h).  torch is used only to own device memory
+and streams; every computation below is a HIP kernel in libgsdd.so."""
+import ctypes as C
+
+import torch
+
+from ._lib import GemmDesc, StepDesc, check, lib, ptr, stream_ptr
+
+ACT_NONE, ACT_RELU, ACT_GELU2 = 0, 1, 2
+_keep = []          # tap tables are tiny device tensors that must outlive the launch
+
+
+def taps_tensor(taps, device):
+    """int32 device table [(dt,dh,dw), ...]"""
+    return torch.tensor(taps, dtype=torch.int32, device=device).contiguous()
+
+
+def gemm(inp, w, out, *, in_dims, out_grid, stride=(1, 1, 1), taps=None, ntaps=1, cin=None, in_pitch=None,
+         gather=None, pro=None, ln=None, epi_scale=None, epi_shift=None, bvec=None, rows_per_batch=0, act=ACT_NONE,
+         residual=None, out_dims=None, out_step=(1, 1, 1), out_off=(0, 0, 0), out_pitch=None, out_mode=0, cout=None,
+         stream=None):
+    """out[orow(m)][n] = epi(sum_tap sum_c pro(in[src(m,tap)][c]) * w[tap][n][c]).
+
+    in_dims = (N, Di, Hi, Wi); out_grid = (Do, Ho, Wo); w: [ntaps][Cout][Cin];
+    pro = (scale, shift) per input channel with ReLU; ln = (stats, gamma, beta, sel, stride)."""
+    d = GemmDesc()
+    N, Di, Hi, Wi = in_dims
+    d.in_ = ptr(inp)
+    d.N, d.Di, d.Hi, d.Wi = N, Di, Hi, Wi
+    d.Cin = cin if cin is not None else w.shape[-1]
+    d.in_pitch = in_pitch if in_pitch is not None else d.Cin
+    d.Do, d.Ho, d.Wo = out_grid
+    d.sd, d.sh, d.sw = stride
+    d.ntaps = ntaps
+    d.taps = ptr(taps)
+    d.gather = ptr(gather)
+    d.w = ptr(w)
+    d.Cout = cout if cout is not None else w.shape[-2]
+    if pro is not None:
+        d.pro_scale, d.pro_shift = ptr(pro[0]), ptr(pro[1])
+    if ln is not None:
+        stats, gamma, beta, sel, ln_stride = ln
+        d.ln_stats, d.ln_gamma, d.ln_beta, d.ln_sel, d.ln_stride = ptr(stats), ptr(gamma), ptr(beta), ptr(sel), ln_stride
+    d.rows_per_batch = rows_per_batch
+    d.epi_scale, d.epi_shift, d.bvec = ptr(epi_scale), ptr(epi_shift), ptr(bvec)
+    d.act = act
+    d.residual = ptr(residual)
+    d.out = ptr(out)
+    od = out_dims if out_dims is not None else out_grid
+    d.oD, d.oH, d.oW = od
+    d.osd, d.osh, d.osw = out_step
+    d.ood, d.ooh, d.oow = out_off
+    d.out_pitch = out_pitch if out_pitch is not None else d.Cout
+    d.out_mode = out_mode
+    check(lib().gsdd_gemm(C.byref(d), stream_ptr(stream)))
+    return out
+
+
+def linear(x, w, out, *, bias=None, ln=None, rows_per_batch=0, act=ACT_NONE, residual=None, bvec=None, out_mode=0,
+           stream=None):
+    """Row GEMM: out[m][:] = act(pro(x[m]) @ w.T + bias [+ bvec[batch]]) [+ residual].  x: [M][Cin], w: [Cout][Cin]."""
+    M = x.shape[0]
+    return gemm(x, w, out, in_dims=(1, 1, 1, M), out_grid=(1, 1, M), ln=ln, epi_shift=bias, bvec=bvec,
+                rows_per_batch=rows_per_batch, act=act, residual=residual, out_mode=out_mode, stream=stream)
+
+
+def row_stats(x, stats, eps=1e-5, stream=None):
+    check(lib().gsdd_row_stats(ptr(x), x.shape[0], x.shape[1], eps, ptr(stats), stream_ptr(stream)))
+    return stats
+
+
+def ncdhw_to_rows(x, cpad, padw, out=None, stream=None):
+    N, Cc, D, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, D, H, W + 2 * padw, cpad), dtype=torch.float32, device=x.device)
+    check(lib().gsdd_ncdhw_to_rows(ptr(x), N, Cc, D, H, W, cpad, padw, ptr(out), stream_ptr(stream)))
+    return out
+
+
+def axial_attention(qkv, dims, C_, n_head, out, stream=None):
+    N, T, H, W = dims
+    check(lib().gsdd_axial_attention(ptr(qkv), N, T, H, W, C_, n_head, ptr(out), stream_ptr(stream)))
+    return out
+
+
+def nearest_code(z, cb, idx, zq=None, stream=None):
+    check(lib().gsdd_nearest_code(ptr(z), z.shape[0], z.shape[1], ptr(cb), cb.shape[0], ptr(idx), ptr(zq),
+                                  stream_ptr(stream)))
+    return idx
+
+
+def d3pm_embed(tok, emb, pos, x, rep=1, stream=None):
+    B, L = tok.shape
+    check(lib().gsdd_d3pm_embed(ptr(tok), B, L, emb.shape[1], ptr(emb), emb.shape[0], ptr(pos), rep, ptr(x),
+                                stream_ptr(stream)))
+    return x
+
+
+def adaln_table(emb_w, lin_w, lin_b, out=None, stream=None):
+    T, D = emb_w.shape
+    if out is None:
+        out = torch.empty((T, 2 * D), dtype=torch.float32, device=emb_w.device)
+    check(lib().gsdd_adaln_table(ptr(emb_w), T, D, ptr(lin_w), ptr(lin_b), ptr(out), stream_ptr(stream)))
+    return out
+
+
+def small_linear(x, w, b, out=None, stream=None):
+    R, Cin = x.shape
+    if out is None:
+        out = torch.empty((R, w.shape[0]), dtype=torch.float32, device=x.device)
+    check(lib().gsdd_small_linear(ptr(x), R, Cin, ptr(w), ptr(b), w.shape[0], ptr(out), stream_ptr(stream)))
+    return out
+
+
+def d3pm_attention(q, k, v, B, L, H, out, stream=None):
+    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), stream_ptr(stream)))
+    return out
+
+
+def d3pm_cross_attention(q, kc, vc, B, L, Te, H, out, stream=None):
+    check(lib().gsdd_d3pm_cross_attention(ptr(q), ptr(kc), ptr(vc), B, L, Te, H, ptr(out), stream_ptr(stream)))
+    return out
+
+
+def d3pm_step(logits_c, logits_u, tok_in, tok_out, sched, t_dev, stream_dev, *, K, T, guidance, seed, row0=0,
+              post_dbg=None, x0_dbg=None, stream=None):
+    B, L = tok_in.shape
+    d = StepDesc()
+    d.logits_c, d.logits_u = ptr(logits_c), ptr(logits_u)
+    d.tok_in, d.tok_out = ptr(tok_in), ptr(tok_out)
+    d.B, d.L, d.K, d.T = B, L, K, T
+    d.guidance = guidance
+    for i in range(8):
+        d.sched[i] = ptr(sched[i])
+    d.t_dev, d.seed, d.stream_dev, d.row0 = ptr(t_dev), seed, ptr(stream_dev), row0
+    d.post_dbg, d.x0_dbg = ptr(post_dbg), ptr(x0_dbg)
+    check(lib().gsdd_d3pm_step(C.byref(d), stream_ptr(stream)))
+    return tok_out
+
+
+def d3pm_q_sample(x0, xt, sched, t_dev, stream_dev, *, K, T, seed, row0=0, stream=None):
+    B, L = x0.shape
+    arr = (C.c_void_p * 8)(*[ptr(s) for s in sched])
+    check(lib().gsdd_d3pm_q_sample(ptr(x0), ptr(xt), B, L, K, T, arr, ptr(t_dev), seed, ptr(stream_dev), row0,
+                                   stream_ptr(stream)))
+    return xt
+
+
+def advance(t_dev, dt, stream_dev, ds, stream=None):
+    B = 0 if t_dev is None else t_dev.numel()
+    check(lib().gsdd_advance(ptr(t_dev), B, dt, ptr(stream_dev), ds, stream_ptr(stream)))
+
+
+def philox_uniform(seed, stream_id, n_rows, n_cols, device, row0=0):
+    out = torch.empty((n_rows, n_cols), dtype=torch.float32, device=device)
+    check(lib().gsdd_philox_uniform(seed, stream_id, row0, n_rows, n_cols, ptr(out), stream_ptr()))
+    return out
+
+
+class Graph:
+    """A captured hipGraph of one reverse step (gsdd_graph_* in include/gsdd.h)."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+
+    def begin(self, stream):
+        check(lib().gsdd_graph_begin(stream_ptr(stream)))
+
+    def end(self, stream):
+        check(lib().gsdd_graph_end(stream_ptr(stream), C.byref(self.handle)))
+
+    def launch(self, stream):
+        check(lib().gsdd_graph_launch(self.handle, stream_ptr(stream)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().gsdd_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Event:
+    """hipEvent recorded on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        check(lib().gsdd_event_create(C.byref(self.h)))
+
+    def record(self, stream=None):
+        check(lib().gsdd_event_record(self.h, stream_ptr(stream)))
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        check(lib().gsdd_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().gsdd_event_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,181 @@
+/*
+ * gsdd.h — C ABI of the MI355X (gfx950) video-token generation hot path.
+ *
+ * Drop-in boundary for the VQ-VAE encode/quantise/decode + D3PM reverse-diffusion path of
+ * Developer-Zer0/GIF-synthesis-with-Discrete-Diffusion.  The reference has NO native FFI for this
+ * path: its seam is Hydra `_target_` instantiation of torch nn.Modules.  Each entry
+ * point below therefore cites the reference *op sequence* (file:line under /root/reference) that
+ * it replaces; the Python shells in gif-synthesis-with-discrete-diffusion_amd/ bind them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch-ROCm storage); the library never
+ *     allocates, frees or synchronises; all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - fp32 everywhere; token / code indices are int64 (torch.argmin/argmax dtype).
+ *   - return 0 on success, <0 on error (GSDD_E_*); gsdd_last_error() gives a message (thread-local).
+ *   - activations are channels-last: a "row" is one position (n,t,h,w) with C contiguous floats.
+ */
+#ifndef GSDD_H
+#define GSDD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSDD_OK 0
+#define GSDD_E_ARG (-1)     /* bad argument (null pointer, unsupported shape)  */
+#define GSDD_E_HIP (-2)     /* a HIP runtime call failed                        */
+#define GSDD_E_STATE (-3)   /* graph capture misuse                             */
+
+const char* gsdd_last_error(void);
+int gsdd_version(void);
+
+/* ------------------------------------------------------------------ generic implicit GEMM
+ * out[orow(m)][n] = epi( sum_{tap,c} pro(in[src(m,tap)][c]) * w[tap][n][c] )
+ * One kernel serves every dense contraction on the VQ-VAE path and the denoiser's linears:
+ *   SamePadConv3d / nn.Conv3d            videogpt_vq_vae.py:289-309   (taps = kt*kh*kw)
+ *   SamePadConvTranspose3d (per phase)   videogpt_vq_vae.py:312-332   (sub-pixel phases)
+ *   nn.Linear                            model_utils.py:223-233, transformer_utils.py:36-43,258-263,353-356
+ * Activation modes (act):  0 none, 1 ReLU, 2 x*sigmoid(1.702x) (GELU2, transformer_utils.py:115-119)
+ */
+typedef struct {
+    /* input tensor: N x Di x Hi x Wi positions, row pitch `in_pitch` floats, Cin used channels */
+    const float* in;
+    int N, Di, Hi, Wi, Cin, in_pitch;
+    /* output grid (positions enumerated (n,to,ho,wo)); rows M = N*Do*Ho*Wo */
+    int Do, Ho, Wo;
+    int sd, sh, sw;                 /* input stride per output step                          */
+    int ntaps;
+    const int* taps;                /* device int[ntaps*3]: (dt,dh,dw) added to o*stride     */
+    const int64_t* gather;          /* optional: in row = gather[m] (ntaps must be 1)        */
+    /* weights: [ntaps][Cout][Cin] floats (Cin contiguous) */
+    const float* w;
+    int Cout;
+    /* prologue on the input operand */
+    const float* pro_scale;         /* per input channel a = relu(x*ps[c]+pb[c]) (BN+ReLU)   */
+    const float* pro_shift;
+    const float* ln_stats;          /* per input row (mean, rstd) pairs -> LayerNorm         */
+    const float* ln_gamma;          /* [sel][Cin]   a = (x-mu)*rs*gamma + beta               */
+    const float* ln_beta;
+    const int64_t* ln_sel;          /* optional per-batch selector (e.g. timestep), else 0   */
+    int ln_stride;                  /* floats between selector rows                          */
+    int rows_per_batch;             /* rows per batch element (for ln_sel / bvec)            */
+    /* epilogue */
+    const float* epi_scale;         /* per output channel, optional                          */
+    const float* epi_shift;         /* per output channel (bias / folded BN), optional       */
+    const float* bvec;              /* optional [batch][Cout] vector added per batch element */
+    int act;
+    const float* residual;          /* optional, same addressing as out                      */
+    /* output addressing: row = ((n*oD + to*osd+ood)*oH + ho*osh+ooh)*oW + wo*osw+oow         */
+    float* out;
+    int oD, oH, oW, osd, osh, osw, ood, ooh, oow, out_pitch;
+    int out_mode;                   /* 0 channels-last rows; 1 NCDHW (out[n][c][d][h][w]);
+                                       2 head-major [n/4][M][4] (denoiser q/k/v)             */
+} gsdd_gemm_desc;
+int gsdd_gemm(const gsdd_gemm_desc* d, void* stream);
+
+/* per-row LayerNorm statistics (mean, rstd) of x[M][C] (eps inside rsqrt).
+ * Replaces the statistics half of nn.LayerNorm: transformer_utils.py:147,157,217,354 */
+int gsdd_row_stats(const float* x, int64_t M, int C, float eps, float* stats, void* stream);
+
+/* ------------------------------------------------------------------ layout at the NCDHW boundary
+ * videogpt_vq_vae.py:58-60 hands (B,3,T,H,W); kernels are channels-last. */
+int gsdd_ncdhw_to_rows(const float* x, int N, int C, int D, int H, int W, int Cpad, int padw,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------ VQ-VAE specific
+ * Axial attention over one axis of a (N,T,H,W) grid of fused q|k|v rows.
+ * qkv row layout: [9*C] = (axis a: q,k,v) for a in (w,h,t); out row layout [3*C] = (a_w|a_h|a_t).
+ * Replaces AxialAttention + scaled_dot_product_attention: model_utils.py:318-337, :586-600. */
+int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W, int C, int n_head,
+                         float* out, void* stream);
+
+/* Nearest codebook entry: idx[m] = argmin_k (|z_m|^2 - 2 z_m.e_k + |e_k|^2), first minimum wins.
+ * Replaces Codebook.forward distance+argmin: videogpt_vq_vae.py:178-183.
+ * z: [M][E] rows, cb: [K][E]; optional zq[M][E] = cb[idx] (the F.embedding at :186). */
+int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K,
+                      int64_t* idx, float* zq, void* stream);
+
+/* ------------------------------------------------------------------ D3PM denoiser pieces
+ * x[b][l][:] = emb[tok[b][l]] + pos[l]   (DalleMaskImageEmbedding.forward, dalle_mask_image_embedding.py:59-79;
+ * pos = height_emb[l/W]+width_emb[l%W] precomputed once). rep: x is written for `rep` stacked copies. */
+int gsdd_d3pm_embed(const int64_t* tok, int B, int L, int D, const float* emb, int n_embed,
+                    const float* pos, int rep, float* x, void* stream);
+
+/* AdaLayerNorm modulation table: out[t][0:D] = 1+scale, out[t][D:2D] = shift with
+ * [scale|shift] = Linear(SiLU(emb[t]))  (AdaLayerNorm, transformer_utils.py:138-159). */
+int gsdd_adaln_table(const float* emb, int T, int D, const float* lin_w, const float* lin_b,
+                     float* out, void* stream);
+
+/* y[r][:] = W x[r] + b for a handful of rows (cross-attention value/proj of the condition token,
+ * transformer_utils.py:95-113 with T_E == 1: softmax over one key == 1). */
+int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const float* b, int Cout,
+                      float* y, void* stream);
+
+/* Self-attention for head dim 4: q,k,v head-major [H][M][4] (M = B*L rows), out rows [M][H*4].
+ * softmax(q k^T / sqrt(4)) v, scores never leave registers.
+ * Replaces FullAttention.forward: transformer_utils.py:46-62 (head-mean att is dropped: unused). */
+int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
+                        float* out, void* stream);
+
+/* General cross-attention (T_E condition tokens), head dim 4; q head-major [H][M][4],
+ * kc/vc rows [B*Te][H*4]; out rows [M][H*4].  transformer_utils.py:95-113. */
+int gsdd_d3pm_cross_attention(const float* q, const float* kc, const float* vc, int B, int L, int Te,
+                              int H, float* out, void* stream);
+
+/* One fused reverse-diffusion step on int64 tokens:
+ *   predict_start (fp log_softmax, clamp) x2 -> cf guidance mix -> q_posterior -> Gumbel arg-max.
+ * Replaces diffusion_transformer.py:220-249 (predict_start/cf_predict_start tails), :251-283
+ * (q_posterior), :354-359 (log_sample_categorical) and the log-one-hot round trip (:44-54).
+ * logits_c / logits_u: [B*L][K] rows (logits_u may be NULL -> no guidance: predict_start only).
+ * sched: 8 device arrays in the order log_at, log_bt, log_ct, log_1_min_ct (T each),
+ *        log_cumprod_at, log_cumprod_bt, log_cumprod_ct, log_1_min_cumprod_ct (T+1 each).
+ * t_dev: device int64[B] timesteps; stream_dev: device int64[1] Philox stream id (both read on
+ * device so a captured graph can be replayed).  post_dbg: optional [B][K+1][L] log-probabilities.
+ * x0_dbg: optional [B][K+1][L] guided log p(x0|xt) (cf_predict_start output). */
+typedef struct {
+    const float* logits_c;
+    const float* logits_u;
+    const int64_t* tok_in;
+    int64_t* tok_out;
+    int B, L, K, T;
+    float guidance;
+    const float* sched[8];
+    const int64_t* t_dev;
+    uint64_t seed;
+    const int64_t* stream_dev;
+    int64_t row0;               /* global row offset of this shard (multi-GPU batch split)   */
+    float* post_dbg;
+    float* x0_dbg;
+} gsdd_step_desc;
+int gsdd_d3pm_step(const gsdd_step_desc* d, void* stream);
+
+/* q_sample for training: tok_out = Gumbel-argmax(q_pred(onehot(x0), t)), diffusion_transformer.py:361-366 */
+int gsdd_d3pm_q_sample(const int64_t* x0, int64_t* xt, int B, int L, int K, int T,
+                       const float* const* sched, const int64_t* t_dev, uint64_t seed,
+                       const int64_t* stream_dev, int64_t row0, void* stream);
+
+/* t[b] += dt ; stream[0] += ds   (device-side loop counters for the captured step graph) */
+int gsdd_advance(int64_t* t_dev, int B, int64_t dt, int64_t* stream_dev, int64_t ds, void* stream);
+
+/* uniform Philox floats, layout of oracle/philox.py uniform_rows (test hook) */
+int gsdd_philox_uniform(uint64_t seed, int64_t stream_id, int64_t row0, int64_t n_rows, int n_cols,
+                        float* out, void* stream);
+
+/* ------------------------------------------------------------------ hipGraph capture of a step
+ * (the 100-iteration loop at diffusion_transformer.py:621-626 becomes 100 replays). */
+int gsdd_graph_begin(void* stream);
+int gsdd_graph_end(void* stream, void** graph_exec_out);
+int gsdd_graph_launch(void* graph_exec, void* stream);
+int gsdd_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on a given stream (bench.py measures the stream the kernels run on) */
+int gsdd_event_create(void** ev);
+int gsdd_event_record(void* ev, void* stream);
+int gsdd_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises ev_stop */
+int gsdd_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSDD_H */

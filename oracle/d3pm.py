@@ -177,9 +177,10 @@ def q_posterior(log_x_start, log_x_t, t, sd):
 
 
 def gumbel_argmax(logits, seed, stream):
-    """Reference: log_sample_categorical, diffusion_transformer.py:354-359, with Philox uniforms."""
+    """Reference: log_sample_categorical, diffusion_transformer.py:354-359, with Philox uniforms
+    (seed=None: torch.rand_like as in the reference, used for CPU-baseline timing only)."""
     B, K1, L = logits.shape
-    u = torch.from_numpy(philox.uniform_bkl(seed, stream, B, K1, L))
+    u = torch.rand_like(logits) if seed is None else torch.from_numpy(philox.uniform_bkl(seed, stream, B, K1, L))
     g = -torch.log(-torch.log(u + 1e-30) + 1e-30)
     return (g + logits).argmax(dim=1)
 
