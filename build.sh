@@ -11,7 +11,7 @@ for f in $SRC/*.hip; do
   o="build/$(basename "${f%.hip}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ include/gsdd.h -nt "$o" ]; then
     echo "hipcc $f"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function \
         -c "$f" -o "$o" &
   fi
   OBJS="$OBJS $o"

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at the C3 workload shapes (HIP events on the launch stream)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gsdd_amd  # noqa: E402
+from gsdd_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=2):
+    st = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    e0, e1 = ops.Event(), ops.Event()
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    return e0.elapsed_ms(e1) / iters
+
+
+def main():
+    which = sys.argv[1:] or ["attn", "gemm", "step"]
+    dev = "cuda"
+    B2, L, H, D, K = 32, 4096, 16, 64, 4096
+    M = B2 * L
+    if "attn" in which:
+        q = torch.randn((3 * H, M, 4), device=dev)
+        out = torch.empty((M, H * 4), device=dev)
+        ms = timeit(lambda: ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out))
+        fl = 16.0 * L * L * H * B2
+        print(f"attention  B2={B2} L={L}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
+    if "gemm" in which:
+        x = torch.randn((M, D), device=dev)
+        stats = torch.empty((M, 2), device=dev)
+        g = torch.randn((100, 2 * D), device=dev)
+        t2 = torch.full((B2,), 50, dtype=torch.int64, device=dev)
+        for (name, cin, cout, ln, act, mode, res) in [("qkv", 64, 192, True, 0, 2, False), ("proj", 64, 64, False, 0, 0, True),
+                                                      ("mlp1", 64, 256, True, 2, 0, False), ("mlp2", 256, 64, False, 0, 0, True),
+                                                      ("logits", 64, K, True, 0, 0, False)]:
+            w = torch.randn((cout, cin), device=dev) * 0.05
+            b = torch.randn((cout,), device=dev)
+            a = torch.randn((M, cin), device=dev)
+            o = torch.empty((M, cout), device=dev)
+            r = torch.randn((M, cout), device=dev) if res else None
+            lnarg = (stats, g.view(-1), g.view(-1)[D:], t2, 2 * D) if ln else None
+            ops.row_stats(x, stats)
+            ms = timeit(lambda: ops.linear(a, w, o, bias=b, ln=lnarg, rows_per_batch=L, act=act, residual=r, out_mode=mode))
+            fl = 2.0 * M * cin * cout
+            by = 4.0 * M * (cin + cout * (2 if res else 1))
+            print(f"gemm {name:7s} {cin}->{cout}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  {by / ms / 1e6:.0f} GB/s")
+        ms = timeit(lambda: ops.row_stats(x, stats))
+        print(f"row_stats: {ms:.3f} ms  {4.0 * M * D / ms / 1e6:.0f} GB/s")
+    if "step" in which:
+        Bs = B2 // 2
+        logits = torch.randn((M, K), device=dev)
+        tok = torch.randint(0, K + 1, (Bs, L), device=dev)
+        t = torch.full((B2,), 50, dtype=torch.int64, device=dev)
+        sid = torch.zeros(1, dtype=torch.int64, device=dev)
+        d = gsdd_amd.DalleMaskImageEmbedding(num_embed=K, spatial_size=[64, 64], embed_dim=64)
+        tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                            content_spatial_size=[64, 64], diffusion_step=100)
+        dm = gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", guidance_scale=2,
+                                           content_seq_len=L).cuda()
+        Mh = Bs * L
+        ms = timeit(lambda: ops.d3pm_step(logits[:Mh], logits[Mh:], tok, tok, dm._sched(), t, sid, K=K, T=100, guidance=2.0, seed=1))
+        by = 2.0 * Mh * K * 4
+        print(f"d3pm_step B={Bs}: {ms:.3f} ms  {by / ms / 1e6:.0f} GB/s algorithmic")
+
+
+if __name__ == "__main__":
+    main()
