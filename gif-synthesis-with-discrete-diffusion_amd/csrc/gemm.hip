@@ -54,22 +54,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     for (int j = 0; j < 4; ++j) {
         const int64_t m = bm0 + r0 + 32 * j;
         rvalid[j] = m < M;
-        const int64_t mm = rvalid[j] ? m : 0;
+        const uint32_t mm = rvalid[j] ? (uint32_t)m : 0u;          // M < 2^31 (checked on the host)
         if (d.gather != nullptr) {
             nb[j] = rvalid[j] ? d.gather[mm] : 0;
             ti0[j] = hi0[j] = wi0[j] = 0;
         } else {
-            int64_t q = mm;
-            const int wo = (int)(q % d.Wo); q /= d.Wo;
-            const int ho = (int)(q % d.Ho); q /= d.Ho;
-            const int to = (int)(q % d.Do); q /= d.Do;
+            uint32_t q = mm;
+            const uint32_t wo = q % (uint32_t)d.Wo; q /= (uint32_t)d.Wo;
+            const uint32_t ho = q % (uint32_t)d.Ho; q /= (uint32_t)d.Ho;
+            const uint32_t to = q % (uint32_t)d.Do; q /= (uint32_t)d.Do;
             nb[j] = q;
-            ti0[j] = to * d.sd; hi0[j] = ho * d.sh; wi0[j] = wo * d.sw;
+            ti0[j] = (int)to * d.sd; hi0[j] = (int)ho * d.sh; wi0[j] = (int)wo * d.sw;
         }
         mu[j] = 0.f; rs[j] = 1.f; sel[j] = 0;
         if (d.ln_stats != nullptr) {
-            mu[j] = d.ln_stats[2 * mm]; rs[j] = d.ln_stats[2 * mm + 1];
-            if (d.ln_sel != nullptr) sel[j] = d.ln_sel[mm / d.rows_per_batch];
+            mu[j] = d.ln_stats[2 * (int64_t)mm]; rs[j] = d.ln_stats[2 * (int64_t)mm + 1];
+            if (d.ln_sel != nullptr) sel[j] = d.ln_sel[mm / (uint32_t)d.rows_per_batch];
         }
     }
 
@@ -172,41 +172,48 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     const bool linear_rows = (d.oD == d.Do && d.oH == d.Ho && d.oW == d.Wo && d.osd == 1 && d.osh == 1 && d.osw == 1 &&
                               d.ood == 0 && d.ooh == 0 && d.oow == 0);
     const int64_t ohw = (int64_t)d.oH * d.oW;
+    int ncol[NT];
+    bool nok[NT];
+    float es[NT], eh[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = bn0 + wn * (BN / 2) + nt * 32 + li;
-        const bool nok = n < d.Cout;
-        const float es = (d.epi_scale != nullptr && nok) ? d.epi_scale[n] : 1.f;
-        const float eh = (d.epi_shift != nullptr && nok) ? d.epi_shift[n] : 0.f;
+        ncol[nt] = bn0 + wn * (BN / 2) + nt * 32 + li;
+        nok[nt] = ncol[nt] < d.Cout;
+        es[nt] = (d.epi_scale != nullptr && nok[nt]) ? d.epi_scale[ncol[nt]] : 1.f;
+        eh[nt] = (d.epi_shift != nullptr && nok[nt]) ? d.epi_shift[ncol[nt]] : 0.f;
+    }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = bm0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= M || !nok) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = bm0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= M) continue;
+            const uint32_t mu32 = (uint32_t)m;
+            int64_t orow = m, bidx = 0, od = 0, rem = 0;
+            if (d.out_mode != 2 && (!linear_rows || d.out_mode == 1)) {
+                uint32_t q = mu32;
+                const uint32_t wo = q % (uint32_t)d.Wo; q /= (uint32_t)d.Wo;
+                const uint32_t ho = q % (uint32_t)d.Ho; q /= (uint32_t)d.Ho;
+                const uint32_t to = q % (uint32_t)d.Do; q /= (uint32_t)d.Do;
+                bidx = q;
+                od = (int64_t)to * d.osd + d.ood;
+                rem = (int64_t)((int)ho * d.osh + d.ooh) * d.oW + ((int)wo * d.osw + d.oow);
+                orow = (bidx * d.oD + od) * ohw + rem;
+            }
+            const float* bv = d.bvec != nullptr ? d.bvec + (int64_t)(mu32 / (uint32_t)d.rows_per_batch) * d.Cout : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (!nok[nt]) continue;
+                const int n = ncol[nt];
                 float v = acc[mt][nt][r];
-                if (d.epi_scale != nullptr) v *= es;
-                v += eh;
-                if (d.bvec != nullptr) v += d.bvec[(m / d.rows_per_batch) * d.Cout + n];
+                if (d.epi_scale != nullptr) v *= es[nt];
+                v += eh[nt];
+                if (bv != nullptr) v += bv[n];
                 v = act_fn(v, d.act);
                 int64_t addr;
-                if (d.out_mode == 2) {
-                    addr = ((int64_t)(n >> 2) * M + m) * 4 + (n & 3);
-                } else {
-                    int64_t orow = m, bidx = 0, od = 0, rem = 0;
-                    if (!linear_rows || d.out_mode == 1) {
-                        int64_t q = m;
-                        const int wo = (int)(q % d.Wo); q /= d.Wo;
-                        const int ho = (int)(q % d.Ho); q /= d.Ho;
-                        const int to = (int)(q % d.Do); q /= d.Do;
-                        bidx = q;
-                        od = (int64_t)to * d.osd + d.ood;
-                        rem = (int64_t)(ho * d.osh + d.ooh) * d.oW + (wo * d.osw + d.oow);
-                        orow = (bidx * d.oD + od) * ohw + rem;
-                    }
-                    if (d.out_mode == 1) addr = ((bidx * d.Cout + n) * d.oD + od) * ohw + rem;
-                    else addr = orow * d.out_pitch + n;
-                }
+                if (d.out_mode == 2) addr = ((int64_t)(n >> 2) * M + m) * 4 + (n & 3);
+                else if (d.out_mode == 1) addr = ((bidx * d.Cout + n) * d.oD + od) * ohw + rem;
+                else addr = orow * d.out_pitch + n;
                 if (d.residual != nullptr) v += d.residual[addr];
                 d.out[addr] = v;
             }
@@ -281,6 +288,7 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
     GSDD_CHECK_ARG(d->out_mode == 2 || (d->oD > 0 && d->oH > 0 && d->oW > 0), "bad output dims");
     GSDD_CHECK_ARG(d->out_mode != 0 || d->out_pitch >= d->Cout, "out_pitch too small");
     const int64_t M = (int64_t)d->N * d->Do * d->Ho * d->Wo;
+    GSDD_CHECK_ARG(M < (1ll << 31), "more than 2^31 rows");
     hipStream_t st = (hipStream_t)stream;
     const unsigned gx = (unsigned)((M + BM - 1) / BM);
     if (d->Cout > 64) {
