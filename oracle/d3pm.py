@@ -176,16 +176,16 @@ def q_posterior(log_x_start, log_x_t, t, sd):
     return torch.clamp(q_pred(q, t - 1, sd) + log_q1 + s, -70, 0)
 
 
-def gumbel_argmax(logits, seed, stream):
+def gumbel_argmax(logits, seed, stream, row0=0):
     """Reference: log_sample_categorical, diffusion_transformer.py:354-359, with Philox uniforms
     (seed=None: torch.rand_like as in the reference, used for CPU-baseline timing only)."""
     B, K1, L = logits.shape
-    u = torch.rand_like(logits) if seed is None else torch.from_numpy(philox.uniform_bkl(seed, stream, B, K1, L))
+    u = torch.rand_like(logits) if seed is None else torch.from_numpy(philox.uniform_bkl(seed, stream, B, K1, L, row0=row0))
     g = -torch.log(-torch.log(u + 1e-30) + 1e-30)
     return (g + logits).argmax(dim=1)
 
 
-def p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream, first=False, n_head=16):
+def p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream, first=False, n_head=16, row0=0):
     """One reverse step on int tokens.  Reference: p_sample/p_pred, diffusion_transformer.py:285-352
     (prior_rule == 0 branch).  ``first``: the all-[MASK] start uses true -inf rows (:613-618)."""
     K1 = sd["transformer.content_emb.emb.weight"].shape[0]
@@ -196,17 +196,20 @@ def p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream, first=False, n
         log_z = index_to_log_onehot(tok, K1)
     rec = cf_predict_start(log_z, cond, cf_cond, t, sd, scale, n_head)
     post = q_posterior(rec, log_z, t, sd)
-    return gumbel_argmax(post, seed, stream), post
+    return gumbel_argmax(post, seed, stream, row0=row0), post
 
 
-def sample(B, L, cond, cf_cond, sd, scale, seed, n_head=16, trace=None):
+def sample(B, L, cond, cf_cond, sd, scale, seed, n_head=16, trace=None, row0=0, steps=None):
     """Reference: DiffusionTransformer.sample with filter_ratio=0, diffusion_transformer.py:568-644."""
     T = sd["log_at"].shape[0]
     K1 = sd["transformer.content_emb.emb.weight"].shape[0]
     tok = torch.full((B, L), K1 - 1, dtype=torch.long)
     for i, step in enumerate(range(T - 1, -1, -1)):
+        if steps is not None and i >= steps:
+            break
         t = torch.full((B,), step, dtype=torch.long)
-        tok, _ = p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream=i, first=(i == 0), n_head=n_head)
+        tok, _ = p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream=i, first=(i == 0), n_head=n_head,
+                               row0=row0)
         if trace is not None:
             trace.append(tok.clone())
     return tok

@@ -1,0 +1,18 @@
+"""`python src/eval.py model=discrete_diffusion ...` (reference: src/eval.py:8-13)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import src  # noqa: E402,F401
+from gsdd_amd.hydra_lite import compose  # noqa: E402
+
+
+def main(argv=None):
+    cfg = compose(os.path.join(ROOT, "configs"), "eval.yaml", list(argv if argv is not None else sys.argv[1:]))
+    from src.tasks.runner import evaluate
+    return evaluate(cfg)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Stage-2 wrapper (D3PM over VQ-VAE tokens): same constructor keys / hooks as the reference's
+MultistageTextMotionModel (src/models/multistage_text_motion_model.py:31-252).  The autoencoder runs in eval()
+(the reference leaves it in train mode by accident)."""
+import torch
+
+from gsdd_amd.hydra_lite import instantiate
+from src.models.base import BaseModel
+
+
+class MultistageTextMotionModel(BaseModel):
+    def __init__(self, generator, autoencoder, generator_losses=None, checkpoint_paths=None, evaluator=None,
+                 freeze_models_dict=None, lr_args={}, render_animations=True, do_evaluation=False, devices="cpu",
+                 **kwargs):
+        super().__init__()
+        self.gpu_device = devices if devices == "cpu" else "cuda:" + str(devices[0])
+        self.generator = instantiate(generator) if isinstance(generator, dict) else generator
+        self.autoencoder = instantiate(autoencoder, device=self.gpu_device, _recursive_=False) \
+            if isinstance(autoencoder, dict) else autoencoder
+        ckpt = (checkpoint_paths or {}).get("autoencoder") if isinstance(checkpoint_paths, dict) else checkpoint_paths
+        if ckpt and ckpt != "__None__":
+            state = torch.load(ckpt, map_location="cpu", weights_only=True)
+            self.autoencoder.load_state_dict(state.get("state_dict", state))
+        self.autoencoder.eval()
+        self.lr_args = dict(lr_args)
+        self.do_evaluation = do_evaluation
+        self.automatic_optimization = False
+
+    def generator_step(self, batch):
+        return dict(self.generator(batch, self.autoencoder, None))
+
+    @torch.no_grad()
+    def sample_generator_step(self, batch):
+        clips = self.generator.sample_videos(batch["text"], self.autoencoder)
+        return {"pred_data": clips, "gt_data": batch.get("video")}
+
+    def allsplit_step(self, split, batch, batch_idx):
+        if split == "train":
+            out = self.generator_step(batch)
+            loss = torch.mean(out["losses"])
+            self.log_dict({f"total/{split}": float(loss)})
+            return loss
+        return self.sample_generator_step(batch)
+
+    def configure_optimizers(self):
+        return [torch.optim.Adam(self.generator.parameters(), lr=self.lr_args.get("gen_lr", 1e-4), betas=(0.5, 0.999)),
+                torch.optim.Adam(self.autoencoder.parameters(), lr=self.lr_args.get("auto_lr", 1e-6))]

@@ -1,0 +1,108 @@
+"""CPU tests of the host side: config composition / instantiation through the reference's `_target_` paths,
+weight repacking, C-ABI symbol export, state_dict key compatibility."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gsdd_amd
+    if not os.path.exists(gsdd_amd.LIB_PATH):
+        subprocess.check_call(["bash", os.path.join(REPO, "build.sh")], cwd=REPO)
+    header = open(os.path.join(REPO, "include", "gsdd.h")).read()
+    declared = set(re.findall(r"\b(gsdd_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(gsdd_amd.EXPORTS), declared ^ set(gsdd_amd.EXPORTS)
+    L = ctypes.CDLL(gsdd_amd.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert gsdd_amd.lib().gsdd_version() >= 100
+
+
+def test_cpu_inputs_fail_loudly_without_fallback():
+    import gsdd_amd
+    m = gsdd_amd.VQVAE(None, 8, 32, 16, 1, [1, 4, 4], 4, 16).eval()
+    with pytest.raises(gsdd_amd.GsddError):
+        m.encode(torch.randn(1, 3, 4, 16, 16))
+    with pytest.raises(gsdd_amd.GsddError):
+        m.decode(torch.zeros(1, 4, 4, 4, dtype=torch.long))
+
+
+def test_compose_and_instantiate_reference_targets():
+    import src  # noqa: F401
+    from gsdd_amd.hydra_lite import compose, instantiate
+    cfg = compose(os.path.join(REPO, "configs"), "eval.yaml", ["batch_size=2", "datamodule.sequence_length=4",
+                                                                "datamodule.resolution=32",
+                                                                "model.generator.diffusion_model.transformer.n_layer=2"])
+    assert cfg.model._target_ == "src.models.multistage_text_motion_model.MultistageTextMotionModel"
+    assert cfg.model.autoencoder.sequence_length == 4 and cfg.datamodule.batch_size == 2
+    assert cfg.model.generator.diffusion_model.transformer.dalle.num_embed == 4096
+    model = instantiate(cfg.model, _recursive_=False)
+    assert type(model.autoencoder).__name__ == "VQVAE" and model.autoencoder.latent_shape == (4, 4, 4)
+    tr = model.generator.diffusion_model.transformer
+    assert len(tr.blocks) == 2 and tr.content_emb.num_embed == 4097
+    cfg1 = compose(os.path.join(REPO, "configs"), "train.yaml", ["model=videogpt_vq_vae"])
+    m1 = instantiate(cfg1.model, _recursive_=False)
+    assert m1.generator.n_codes == 4096 and len(list(m1.configure_optimizers().param_groups)) == 1
+
+
+def test_state_dict_keys_match_reference(golden):
+    import gsdd_amd
+    sd, _, cfg = golden("vqvae_ds188")
+    m = gsdd_amd.VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"],
+                       cfg["downsample"], cfg["sequence_length"], cfg["resolution"])
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+
+
+def test_convT_phase_tables_cover_every_tap_once():
+    from gsdd_amd.vqvae import convT_phases
+    for stride in [(1, 2, 2), (2, 2, 2), (1, 1, 1)]:
+        pf = tuple((4 - s) // 2 + (4 - s) % 2 for s in stride)
+        seen = []
+        for (_, ks, offs) in convT_phases((4, 4, 4), stride, pf):
+            assert len(ks) == len(offs) == 64 // (stride[0] * stride[1] * stride[2])
+            seen += ks
+        assert sorted(seen) == sorted((a, b, c) for a in range(4) for b in range(4) for c in range(4))
+
+
+def test_weight_packing_matches_conv_semantics():
+    """pack_conv_weight / conv_taps / pack_convT_weight reproduce conv3d / conv_transpose3d when applied naively."""
+    from gsdd_amd.vqvae import conv_taps, convT_phases, pack_conv_weight, pack_convT_weight
+    from oracle import vqvae as ov
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 3, 6, 6, generator=g)
+    w = torch.randn(5, 4, 4, 4, 4, generator=g)
+    stride, pf = (1, 2, 2), (2, 1, 1)
+    want = ov.same_pad_conv3d(x, w, None, stride)
+    wp, taps = pack_conv_weight(w), conv_taps((4, 4, 4), stride, pf)
+    got = torch.zeros_like(want)
+    xp = x[0].permute(1, 2, 3, 0)
+    for ti, (dt, dh, dw) in enumerate(taps):
+        for to in range(3):
+            for ho in range(3):
+                for wo in range(3):
+                    t, h, ww = to * stride[0] + dt, ho * stride[1] + dh, wo * stride[2] + dw
+                    if 0 <= t < 3 and 0 <= h < 6 and 0 <= ww < 6:
+                        got[0, :, to, ho, wo] += wp[ti] @ xp[t, h, ww]
+    torch.testing.assert_close(got, want, atol=1e-4, rtol=1e-4)
+    wt = torch.randn(4, 5, 4, 4, 4, generator=g)
+    want = ov.same_pad_convT3d(x, wt, None, stride)
+    got = torch.zeros_like(want)
+    for (ph, ks, offs) in convT_phases((4, 4, 4), stride, pf):
+        wp = pack_convT_weight(wt, ks)
+        for ti, (dt, dh, dw) in enumerate(offs):
+            for to in range(3):
+                for ho in range(6):
+                    for wo in range(6):
+                        t, h, ww = to + dt, ho + dh, wo + dw
+                        if 0 <= t < 3 and 0 <= h < 6 and 0 <= ww < 6:
+                            got[0, :, to * stride[0] + ph[0], ho * stride[1] + ph[1], wo * stride[2] + ph[2]] += wp[ti] @ xp[t, h, ww]
+    torch.testing.assert_close(got, want, atol=1e-4, rtol=1e-4)
