@@ -13,7 +13,7 @@ _lib = None
 EXPORTS = [
     "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
     "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
-    "gsdd_d3pm_attention", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_advance",
+    "gsdd_d3pm_attention", "gsdd_d3pm_layer", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
     "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
 ]
@@ -46,6 +46,14 @@ class StepDesc(C.Structure):
     ]
 
 
+class LayerDesc(C.Structure):
+    _fields_ = [
+        ("y", _p), ("x", _p), ("M", _i64), ("L", _i), ("n_embd", _i), ("hidden", _i), ("cvec", _p),
+        ("wproj", _p), ("bproj", _p), ("ln2_g", _p), ("ln2_b", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p),
+        ("ada", _p), ("t2", _p), ("wqkv", _p), ("bqkv", _p), ("qkv", _p),
+    ]
+
+
 class GsddError(RuntimeError):
     pass
 
@@ -68,6 +76,7 @@ def lib():
         L.gsdd_adaln_table.argtypes = [_p, _i, _i, _p, _p, _p, _p]
         L.gsdd_small_linear.argtypes = [_p, _i, _i, _p, _p, _i, _p, _p]
         L.gsdd_d3pm_attention.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p]
+        L.gsdd_d3pm_layer.argtypes = [C.POINTER(LayerDesc), _p]
         L.gsdd_d3pm_cross_attention.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p]
         L.gsdd_d3pm_step.argtypes = [C.POINTER(StepDesc), _p]
         L.gsdd_d3pm_q_sample.argtypes = [_p, _p, _i, _i, _i, _i, C.POINTER(_p), _p, C.c_uint64, _p, _i64, _p]

@@ -1,0 +1,265 @@
+// Fused "post-attention" half of a D3PM denoiser block, n_embd = 64, for one 32-row group per wave:
+//
+//   x1 = x + proj(y) + b_proj + c_cross[b]                     (attn1 residual + T_E==1 cross-attention vector)
+//   x2 = x1 + W2 GELU2(W1 LN2(x1) + b1) + b2                   (MLP residual)                 -> x (in place)
+//   qkv_next = Wqkv AdaLN_next(x2, t) + b_qkv                   (next block's q|k|v, head-major)   [optional]
+//
+// Replaces Block.forward's tail (transformer_utils.py:268-282), AdaLayerNorm (:150-159), nn.LayerNorm, the MLP
+// (:258-263) and the next block's query/key/value linears (:48-50).
+//
+// Layout trick: every GEMM is computed TRANSPOSED on v_mfma_f32_32x32x2_f32 (A = weights, B = activations), so an
+// accumulator tile has the ROW m on the lane (col = lane&31) and 16 of a tile's 32 features in its registers
+// (feature = 8*(r>>2) + 4*(lane>>5) + (r&3)).  The next GEMM contracts over exactly those features, so register r
+// of the accumulator IS the B operand of MFMA step r (the weight fragment is read in the same permuted k order):
+// activations never leave registers between the four chained GEMMs; LayerNorm needs one cross-half shuffle.
+// W1/W2 (128 KiB) live in LDS for the whole persistent workgroup, W_proj / W_qkv stream from L2.
+#include "common.hpp"
+
+namespace gsdd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D = 64;          // n_embd
+constexpr int HID = 256;       // mlp hidden
+constexpr int W1P = 68;        // LDS pitch of W1 rows (k = 64): == 4 (mod 64) -> conflict-free ds_read_b128
+constexpr int W2P = 260;       // LDS pitch of W2 rows (k = 256)
+
+struct LayerArgs {
+    const float* y;            // [M][64] attention output
+    float* x;                  // [M][64] residual stream (in/out)
+    int64_t M;
+    int L;                     // rows per batch element
+    const float* cvec;         // [B2][64] or null
+    const float* wproj; const float* bproj;
+    const float* ln2_g; const float* ln2_b;
+    const float* w1; const float* b1;      // [256][64], [256]
+    const float* w2; const float* b2;      // [64][256], [64]
+    // next block (optional)
+    const float* ada;          // [T][128] = (1+scale | shift)
+    const int64_t* t2;         // [B2]
+    const float* wqkv; const float* bqkv;  // [192][64], [192]
+    float* qkv;                // [48][M][4]
+};
+
+__device__ __forceinline__ float gelu2(float v) { return v * (1.f / (1.f + expf(-1.702f * v))); }
+
+// fragment helpers: lane (m = lane&31, h = lane>>5) owns features f(t,g,e) = 32t + 8g + 4h + e in reg 16t + 4g + e
+__device__ __forceinline__ void load_frag(const float* row, int h, float (&r)[32]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(row + 32 * t + 8 * g + 4 * h);
+            r[16 * t + 4 * g + 0] = v.x; r[16 * t + 4 * g + 1] = v.y; r[16 * t + 4 * g + 2] = v.z; r[16 * t + 4 * g + 3] = v.w;
+        }
+}
+
+// acc[nt] (features 32nt..32nt+31 of the output) += W[n][k] * act[k], k over the 64 features held in `act`;
+// W rows start at `w` with pitch `pitch` floats, column offset k0
+template <bool LDS_W>
+__device__ __forceinline__ void gemm64(const float* w, int pitch, int k0, int li, int h, const float (&act)[32],
+                                       f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 a0 = *reinterpret_cast<const float4*>(w + (int64_t)li * pitch + k0 + 32 * t + 8 * g + 4 * h);
+            float4 a1 = *reinterpret_cast<const float4*>(w + (int64_t)(32 + li) * pitch + k0 + 32 * t + 8 * g + 4 * h);
+            const int r = 16 * t + 4 * g;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, act[r + 0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, act[r + 0], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, act[r + 1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, act[r + 1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, act[r + 2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, act[r + 2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, act[r + 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, act[r + 3], acc[1], 0, 0, 0);
+        }
+}
+
+__device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+}
+
+// LayerNorm over the 64 features of each row: own 32 registers + the partner half (lane ^ 32)
+__device__ __forceinline__ void row_norm(const float (&v)[32], float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += v[i];
+    s += __shfl_xor(s, 32);
+    mean = s * (1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float dlt = v[i] - mean; q += dlt * dlt; }
+    q += __shfl_xor(q, 32);
+    rstd = 1.0f / sqrtf(q * (1.f / 64.f) + 1e-5f);
+}
+
+template <bool HAS_QKV>
+__global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sw1 = lds;                    // [256][68]
+    float* sw2 = lds + HID * W1P;        // [64][260]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < HID * (D / 4); i += 512) {             // W1 [256][64]
+        const int n = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<float4*>(&sw1[n * W1P + c]) = *reinterpret_cast<const float4*>(a.w1 + n * D + c);
+    }
+    for (int i = tid; i < D * (HID / 4); i += 512) {             // W2 [64][256]
+        const int n = i >> 6, c = (i & 63) * 4;
+        *reinterpret_cast<float4*>(&sw2[n * W2P + c]) = *reinterpret_cast<const float4*>(a.w2 + n * HID + c);
+    }
+    __syncthreads();
+
+    const int64_t ngroups = (a.M + 31) / 32;
+    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
+        const int64_t m = grp * 32 + li;
+        const bool valid = m < a.M;
+        const int64_t mc = valid ? m : a.M - 1;
+        const int b = (int)((uint32_t)mc / (uint32_t)a.L);
+
+        float act[32], x1[32];
+        f32x16 acc[2];
+        // ---- x1 = x + proj(y) + b_proj + cvec[b]
+        load_frag(a.y + mc * D, h, act);
+        zero2(acc);
+        gemm64<false>(a.wproj, D, 0, li, h, act, acc);
+        load_frag(a.x + mc * D, h, x1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bp = *reinterpret_cast<const float4*>(a.bproj + f);
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += (acc[t][r + 0] + bp.x) + cv.x;
+                x1[16 * t + r + 1] += (acc[t][r + 1] + bp.y) + cv.y;
+                x1[16 * t + r + 2] += (acc[t][r + 2] + bp.z) + cv.z;
+                x1[16 * t + r + 3] += (acc[t][r + 3] + bp.w) + cv.w;
+            }
+        // ---- h = LN2(x1) * gamma + beta
+        float mean, rstd;
+        row_norm(x1, mean, rstd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 gm = *reinterpret_cast<const float4*>(a.ln2_g + f);
+                const float4 bt = *reinterpret_cast<const float4*>(a.ln2_b + f);
+                const int r = 16 * t + 4 * g;
+                act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+            }
+        // ---- MLP in 4 chunks of 64 hidden units; the GELU2 output feeds W2 straight from registers
+        f32x16 acc3[2];
+        zero2(acc3);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            zero2(acc);
+            gemm64<true>(sw1 + c * 64 * W1P, W1P, 0, li, h, act, acc);
+            float u[32];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bb = *reinterpret_cast<const float4*>(a.b1 + 64 * c + 32 * t + 8 * g + 4 * h);
+                    const int r = 4 * g;
+                    u[16 * t + r + 0] = gelu2(acc[t][r + 0] + bb.x);
+                    u[16 * t + r + 1] = gelu2(acc[t][r + 1] + bb.y);
+                    u[16 * t + r + 2] = gelu2(acc[t][r + 2] + bb.z);
+                    u[16 * t + r + 3] = gelu2(acc[t][r + 3] + bb.w);
+                }
+            gemm64<true>(sw2, W2P, 64 * c, li, h, u, acc3);
+        }
+        // ---- x2 = x1 + mlp + b2 -> x
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + f);
+                const int r = 4 * g;
+                float4 o;
+                o.x = x1[16 * t + r + 0] + (acc3[t][r + 0] + bb.x);
+                o.y = x1[16 * t + r + 1] + (acc3[t][r + 1] + bb.y);
+                o.z = x1[16 * t + r + 2] + (acc3[t][r + 2] + bb.z);
+                o.w = x1[16 * t + r + 3] + (acc3[t][r + 3] + bb.w);
+                x1[16 * t + r + 0] = o.x; x1[16 * t + r + 1] = o.y; x1[16 * t + r + 2] = o.z; x1[16 * t + r + 3] = o.w;
+                if (valid) *reinterpret_cast<float4*>(a.x + m * D + f) = o;
+            }
+        if (HAS_QKV) {
+            // ---- next block: AdaLN(x2, t) then q|k|v
+            row_norm(x1, mean, rstd);
+            const float* tab = a.ada + a.t2[b] * (2 * D);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = 32 * t + 8 * g + 4 * h;
+                    const float4 gm = *reinterpret_cast<const float4*>(tab + f);
+                    const float4 bt = *reinterpret_cast<const float4*>(tab + D + f);
+                    const int r = 16 * t + 4 * g;
+                    act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                    act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                    act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                    act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+                }
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                zero2(acc);
+                gemm64<false>(a.wqkv + (int64_t)c * 64 * D, D, 0, li, h, act, acc);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = 64 * c + 32 * t + 8 * g + 4 * h;      // 4 consecutive outputs = one head's 4 dims
+                        const float4 bb = *reinterpret_cast<const float4*>(a.bqkv + n);
+                        const int r = 4 * g;
+                        const float4 o = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z,
+                                                     acc[t][r + 3] + bb.w);
+                        if (valid) *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o;
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace gsdd
+
+using namespace gsdd;
+
+extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
+    GSDD_CHECK_ARG(d != nullptr, "null descriptor");
+    GSDD_CHECK_ARG(d->y && d->x && d->wproj && d->bproj && d->ln2_g && d->ln2_b && d->w1 && d->b1 && d->w2 && d->b2,
+                   "null pointer");
+    GSDD_CHECK_ARG(d->M > 0 && d->M < (1ll << 31) && d->L > 0, "bad sizes");
+    GSDD_CHECK_ARG(d->n_embd == 64 && d->hidden == 256, "kernel is specialised for n_embd 64, hidden 256");
+    const bool has_qkv = d->qkv != nullptr;
+    GSDD_CHECK_ARG(!has_qkv || (d->ada && d->t2 && d->wqkv && d->bqkv), "next-block operands missing");
+    LayerArgs a;
+    a.y = d->y; a.x = d->x; a.M = d->M; a.L = d->L; a.cvec = d->cvec;
+    a.wproj = d->wproj; a.bproj = d->bproj; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b;
+    a.w1 = d->w1; a.b1 = d->b1; a.w2 = d->w2; a.b2 = d->b2;
+    a.ada = d->ada; a.t2 = d->t2; a.wqkv = d->wqkv; a.bqkv = d->bqkv; a.qkv = d->qkv;
+    const size_t lds = (size_t)(HID * W1P + D * W2P) * sizeof(float);
+    const int64_t ngroups = (d->M + 31) / 32;
+    const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
+    static bool attr_done = false;
+    if (!attr_done) {
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}

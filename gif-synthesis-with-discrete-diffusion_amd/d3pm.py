@@ -178,9 +178,32 @@ class Text2ImageTransformer(nn.Module):
         M = B2 * L
         x, stats, qkv, y, hbuf, logits = ws["x"], ws["stats"], ws["qkv"], ws["y"], ws["h"], ws["logits"]
         ops.d3pm_embed(tok, p["emb"], p["pos"], x, rep=rep, stream=stream)
-        for li, lay in enumerate(p["layers"]):
+        layers = p["layers"]
+        if Te == 1 and D == 64 and hbuf.shape[1] == 256:
+            # fused path: [AdaLN+qkv] for block 0, then per block attention + one fused kernel that also emits the
+            # next block's q|k|v
             ops.row_stats(x, stats, stream=stream)
-            ops.linear(x, lay["wqkv"], qkv, bias=lay["bqkv"], ln=(stats, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t2, 2 * D),
+            ops.linear(x, layers[0]["wqkv"], qkv, bias=layers[0]["bqkv"],
+                       ln=(stats, layers[0]["ada1"].view(-1), layers[0]["ada1"].view(-1)[D:], t2, 2 * D),
+                       rows_per_batch=L, out_mode=2, stream=stream)
+            for li, lay in enumerate(layers):
+                ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, stream=stream)
+                nxt = layers[li + 1] if li + 1 < len(layers) else None
+                ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, stream=stream)
+        else:
+            self._run_blocks_unfused(layers, condv, Te, t2, ws, B2, L, stream)
+        ops.row_stats(x, stats, stream=stream)
+        ops.linear(x, p["wl"], logits, bias=p["bl"], ln=(stats, p["gf"], p["bf"], None, 0), stream=stream)
+        return logits
+
+    def _run_blocks_unfused(self, layers, condv, Te, t2, ws, B2, L, stream):
+        """General path (any T_E): one launch per operator (transformer_utils.py:266-282 in order)."""
+        D, H = self.n_embd, self.n_head
+        x, stats, qkv, y, hbuf = ws["x"], ws["stats"], ws["qkv"], ws["y"], ws["h"]
+        for li, lay in enumerate(layers):
+            ops.row_stats(x, stats, stream=stream)
+            ops.linear(x, lay["wqkv"], qkv, bias=lay["bqkv"],
+                       ln=(stats, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t2, 2 * D),
                        rows_per_batch=L, out_mode=2, stream=stream)
             ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, stream=stream)
             if Te == 1:
@@ -190,7 +213,8 @@ class Text2ImageTransformer(nn.Module):
                 ops.linear(y, lay["wproj"], x, bias=lay["bproj"], residual=x, stream=stream)
                 ops.row_stats(x, stats, stream=stream)
                 q2 = qkv[0:H]
-                ops.linear(x, lay["wq2"], q2, bias=lay["bq2"], ln=(stats, lay["ada2"].view(-1), lay["ada2"].view(-1)[D:], t2, 2 * D),
+                ops.linear(x, lay["wq2"], q2, bias=lay["bq2"],
+                           ln=(stats, lay["ada2"].view(-1), lay["ada2"].view(-1)[D:], t2, 2 * D),
                            rows_per_batch=L, out_mode=2, stream=stream)
                 ops.d3pm_cross_attention(q2, condv[li][0], condv[li][1], B2, L, Te, H, y, stream=stream)
                 ops.linear(y, lay["wproj2"], x, bias=lay["bproj2"], residual=x, stream=stream)
@@ -198,9 +222,6 @@ class Text2ImageTransformer(nn.Module):
             ops.linear(x, lay["w1"], hbuf, bias=lay["bb1"], ln=(stats, lay["g2"], lay["b2"], None, 0),
                        act=ops.ACT_GELU2, stream=stream)
             ops.linear(hbuf, lay["w2"], x, bias=lay["bb2"], residual=x, stream=stream)
-        ops.row_stats(x, stats, stream=stream)
-        ops.linear(x, p["wl"], logits, bias=p["bl"], ln=(stats, p["gf"], p["bf"], None, 0), stream=stream)
-        return logits
 
     def workspace(self, B2, L, device):
         D, H = self.n_embd, self.n_head

@@ -4,7 +4,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import GemmDesc, StepDesc, check, lib, ptr, stream_ptr
+from ._lib import GemmDesc, LayerDesc, StepDesc, check, lib, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_GELU2 = 0, 1, 2
 _keep = []          # tap tables are tiny device tensors that must outlive the launch
@@ -115,6 +115,18 @@ def small_linear(x, w, b, out=None, stream=None):
 def d3pm_attention(q, k, v, B, L, H, out, stream=None):
     check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), stream_ptr(stream)))
     return out
+
+
+def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, stream=None):
+    """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given)."""
+    d = LayerDesc()
+    d.y, d.x, d.M, d.L, d.n_embd, d.hidden = ptr(y), ptr(x), x.shape[0], L, x.shape[1], lay["w1"].shape[0]
+    d.cvec = ptr(cvec)
+    d.wproj, d.bproj, d.ln2_g, d.ln2_b = ptr(lay["wproj"]), ptr(lay["bproj"]), ptr(lay["g2"]), ptr(lay["b2"])
+    d.w1, d.b1, d.w2, d.b2 = ptr(lay["w1"]), ptr(lay["bb1"]), ptr(lay["w2"]), ptr(lay["bb2"])
+    if nxt is not None:
+        d.ada, d.t2, d.wqkv, d.bqkv, d.qkv = ptr(nxt["ada1"]), ptr(t2), ptr(nxt["wqkv"]), ptr(nxt["bqkv"]), ptr(qkv)
+    check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
 
 
 def d3pm_cross_attention(q, kc, vc, B, L, Te, H, out, stream=None):

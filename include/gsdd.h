@@ -118,6 +118,29 @@ int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const floa
 int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
                         float* out, void* stream);
 
+/* Fused post-attention half of a denoiser block (n_embd 64, hidden 256), rows updated in place:
+ *   x += proj(y)+b_proj+cvec[b];  x += W2 GELU2(W1 LN2(x)+b1)+b2;  [qkv_next = Wqkv AdaLN_next(x,t)+b_qkv, head-major]
+ * Replaces Block.forward's tail (transformer_utils.py:268-282: attn1 proj + residual, T_E==1 cross-attention
+ * vector, ln2, mlp :258-263, residual) and the next block's AdaLayerNorm (:150-159) + query/key/value (:48-50).
+ * qkv == NULL skips the next-block stage (last block). */
+typedef struct {
+    const float* y;             /* [M][64] attention output                         */
+    float* x;                   /* [M][64] residual stream, in/out                  */
+    int64_t M;
+    int L;                      /* rows per batch element                           */
+    int n_embd, hidden;         /* must be 64, 256                                  */
+    const float* cvec;          /* optional [M/L][64] per-batch vector              */
+    const float* wproj; const float* bproj;
+    const float* ln2_g; const float* ln2_b;
+    const float* w1; const float* b1;     /* [256][64], [256]                       */
+    const float* w2; const float* b2;     /* [64][256], [64]                        */
+    const float* ada;           /* next block: [T][128] (1+scale | shift) table     */
+    const int64_t* t2;          /* device int64[M/L] timesteps                      */
+    const float* wqkv; const float* bqkv; /* [192][64], [192]                       */
+    float* qkv;                 /* [48][M][4] or NULL                               */
+} gsdd_layer_desc;
+int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
+
 /* General cross-attention (T_E condition tokens), head dim 4; q head-major [H][M][4],
  * kc/vc rows [B*Te][H*4]; out rows [M][H*4].  transformer_utils.py:95-113. */
 int gsdd_d3pm_cross_attention(const float* q, const float* kc, const float* vc, int B, int L, int Te,

@@ -23,7 +23,7 @@ def timeit(fn, iters=10, warm=2):
 
 
 def main():
-    which = sys.argv[1:] or ["attn", "gemm", "step"]
+    which = sys.argv[1:] or ["attn", "gemm", "layer", "step"]
     dev = "cuda"
     B2, L, H, D, K = 32, 4096, 16, 64, 4096
     M = B2 * L
@@ -54,6 +54,21 @@ def main():
             print(f"gemm {name:7s} {cin}->{cout}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s  {by / ms / 1e6:.0f} GB/s")
         ms = timeit(lambda: ops.row_stats(x, stats))
         print(f"row_stats: {ms:.3f} ms  {4.0 * M * D / ms / 1e6:.0f} GB/s")
+    if "layer" in which:
+        d = gsdd_amd.DalleMaskImageEmbedding(num_embed=K, spatial_size=[64, 64], embed_dim=64)
+        tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                            content_spatial_size=[64, 64], diffusion_step=100).cuda()
+        p = tr.packed()
+        x = torch.randn((M, D), device=dev); y = torch.randn((M, D), device=dev)
+        qkv = torch.empty((3 * H, M, 4), device=dev)
+        cv = torch.randn((B2, D), device=dev)
+        t2 = torch.full((B2,), 50, dtype=torch.int64, device=dev)
+        ms = timeit(lambda: ops.d3pm_layer(y, x, L, p["layers"][0], cvec=cv, nxt=p["layers"][1], t2=t2, qkv=qkv))
+        fl = 2.0 * M * (64 * 64 + 2 * 64 * 256 + 64 * 192)
+        print(f"fused layer (proj+mlp+next qkv): {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+        ms = timeit(lambda: ops.d3pm_layer(y, x, L, p["layers"][0], cvec=cv))
+        fl = 2.0 * M * (64 * 64 + 2 * 64 * 256)
+        print(f"fused layer (proj+mlp, last):    {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
     if "step" in which:
         Bs = B2 // 2
         logits = torch.randn((M, K), device=dev)
