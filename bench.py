@@ -51,17 +51,18 @@ def attention_roofline(B2, L, H, device, iters=10):
     q = torch.randn((3 * H, M, 4), device=device)
     out = torch.empty((M, H * 4), device=device)
     st = torch.cuda.current_stream()
+    aws = gsdd_amd.ops.d3pm_attention_workspace(B2, L, H, device)
     for _ in range(2):
-        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, stream=st)
+        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, ws=aws, stream=st)
     e0, e1 = gsdd_amd.ops.Event(), gsdd_amd.ops.Event()
     e0.record(st)
     for _ in range(iters):
-        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, stream=st)
+        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, ws=aws, stream=st)
     e1.record(st)
     ms = e0.elapsed_ms(e1) / iters
     flops = 16.0 * L * L * H * B2            # QK^T (2*4) + PV (2*4) per score
     tf = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "d3pm_attention_kernel", "achieved": round(tf, 2),
+    return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel (+ d3pm_attn_prep_kernel)", "achieved": round(tf, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": None, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
 

@@ -18,6 +18,8 @@
 // The running max m is an integer (exactly representable, rescale factors are powers of two) and is raised
 // only when a score exceeds it by 2^40 (fp32 headroom): a rare wave-uniform branch.
 // K/V tiles are staged through LDS in chunks of 256 keys, double-buffered.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -68,14 +70,24 @@ __global__ __launch_bounds__(256) void d3pm_attention_kernel(const float* __rest
                                                              float* __restrict__ out) {
     __shared__ AttnSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the query blocks of
+    // one (b,h) -- which all stream the same K/V -- are renumbered to share an XCD (bijective remap; speed only).
+    const int nqb = (L + 255) / 256;
+    const unsigned nwg = gridDim.x;
+    unsigned wg = blockIdx.x;
+    {
+        const unsigned q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int qblk = wg % nqb;
+    const int h = (wg / nqb) % H, b = wg / (nqb * H);
     const int64_t M = (int64_t)B * L;
     const int64_t base = ((int64_t)h * M + (int64_t)b * L) * 4;      // first row of this (b,h)
     const float* qh = q + base;
     const float* kh = k + base;
     const float* vh = v + base;
     const int li = lane & 15, lg = lane >> 4, lj = lane & 3;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    const int q0 = qblk * 256 + wave * 64;
     const int quad = lane & ~3;
 
     if (tid < 16) sm.ones[tid] = (tid == 0 || tid == 1) ? make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
@@ -258,6 +270,275 @@ __global__ __launch_bounds__(256) void d3pm_attention_kernel(const float* __rest
     }
 }
 
+// =====================================================================================================
+// v4: P.V and the softmax row sum on the f16 MATRIX pipe as well.
+//
+// What the f32 datapath still has to do per score is then only: v_exp_f32 + (v_cvt_pk_f16 + v_fma_mix + v_cvt_pk_f16)/score
+// = 1 transcendental + 2 plain VALU ops, instead of 1 + 4 FMA + 1 add.
+//   P = hi + lo           hi = f16(p) (RN), lo = f16(p - hi)       (v_fma_mix_f32 subtracts the f16 half directly)
+//   V = v1 + v2/2^11 + v3/2^22   (f16 pieces, scaled so no piece is subnormal)
+//   D[query][col] = sum_key (hi + lo)[query][key] * [v1 | v2 | v3 | 1][key][col]     2 x v_mfma_f32_16x16x32_f16 per 32 keys
+// f16 x f16 products are exact in the f32 accumulator; the six P x V cross terms keep >= 22 bits of P and all of V.
+// The "1" column yields the row sum for free.
+//
+// f16 range: p' = 2^(s - m) must stay below 2^16, and the largest p' of a row at or above 2^3 (so that the summed
+// absolute rounding of subnormal-range p' stays below 2^-22 of the row sum).  m starts at (max over the first 64 keys)
+// - 3; when an accumulator overflows during a 256-key chunk, that chunk is redone for the affected queries with m += 12
+// (accumulators restored from the chunk-start copy and scaled by the exact 2^-12).  So max(p') stays in [2^3, 2^16).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+struct AttnSmem4 {
+    uint4 k[2][KC][2];             // as AttnSmem.k
+    uint4 v[2][KC / 32][4][16];    // [buf][32-key pair-tile][key group g][col j] -> 8 f16: keys (tile0: 4g+r, tile1: 4g+r)
+    uint4 ones[16];
+};
+
+__device__ __forceinline__ f16x8 as_h8(uint4 u) {
+    union { uint4 u; f16x8 v; } c;
+    c.u = u;
+    return c.v;
+}
+// Split 8 probabilities into packed f16 hi / lo fragments (one MFMA A operand each):
+//   hi = f16(p) round-to-nearest (>= 65520 -> inf, which the overflow screen looks for; v_cvt_pkrtz would saturate)
+//   lo = f16(p - hi), the subtraction done by v_fma_mix_f32 reading the f16 half directly (exact in f32)
+// One asm block; it ends with s_nop 1 because hipcc does not pad the VALU-write -> MFMA-read hazard for registers
+// written inside inline asm (cdna_hip_programming.md section 5.7 item 2): without it the MFMA may read stale operands.
+__device__ __forceinline__ void split_p8(const float (&p)[8], uint4& hi, uint4& lo) {
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %16, %17\n\t"
+        "v_cvt_pk_f16_f32 %1, %18, %19\n\t"
+        "v_cvt_pk_f16_f32 %2, %20, %21\n\t"
+        "v_cvt_pk_f16_f32 %3, %22, %23\n\t"
+        "v_fma_mix_f32 %8, %0, -1.0, %16 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %0, -1.0, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %1, -1.0, %18 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %1, -1.0, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %12, %2, -1.0, %20 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %13, %2, -1.0, %21 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %14, %3, -1.0, %22 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %15, %3, -1.0, %23 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %4, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %5, %10, %11\n\t"
+        "v_cvt_pk_f16_f32 %6, %12, %13\n\t"
+        "v_cvt_pk_f16_f32 %7, %14, %15\n\t"
+        "s_nop 1"
+        : "=&v"(hi.x), "=&v"(hi.y), "=&v"(hi.z), "=&v"(hi.w), "=&v"(lo.x), "=&v"(lo.y), "=&v"(lo.z), "=&v"(lo.w),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
+}
+
+// Pre-split K and V once per (b,h) into the exact LDS images the attention workgroups consume (16 query blocks
+// share them), so staging inside the attention kernel is a plain copy:
+//   Kp[row][2] uint4 : pieces A=[k1|k2], B=[k3|k1] (bf16), slots swapped for (key&15)>=8
+//   Vp[row/32][4][16] uint4 : per 32-key pair-tile, [key group g][col j] -> 8 f16 (tile0 keys 4g+r, tile1 keys 4g+r),
+//                             cols = [v1 | v2*2^11 | v3*2^22 | 1 | 0 0 0]
+__global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                             int64_t rows, uint4* __restrict__ kp, uint4* __restrict__ vp) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;       // row = h*M + b*L + key (L % 32 == 0)
+    if (row >= rows) return;
+    const float4 rk = *reinterpret_cast<const float4*>(k + row * 4);
+    const float4 rv = *reinterpret_cast<const float4*>(v + row * 4);
+    const float ks[4] = {rk.x, rk.y, rk.z, rk.w};
+    uint32_t k1[4], k2[4], k3[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) split3(ks[d], k1[d], k2[d], k3[d]);
+    const int sw = (int)((row >> 3) & 1);
+    kp[row * 2 + sw] = pack8(k1, k2);
+    kp[row * 2 + (sw ^ 1)] = pack8(k3, k1);
+    const float vs[4] = {rv.x, rv.y, rv.z, rv.w};
+    _Float16 col[16];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const _Float16 a = (_Float16)vs[d];
+        const float r1 = (vs[d] - (float)a) * 2048.f;
+        const _Float16 b2 = (_Float16)r1;
+        const float r2 = (r1 - (float)b2) * 2048.f;
+        col[d] = a; col[4 + d] = b2; col[8 + d] = (_Float16)r2;
+    }
+    col[12] = (_Float16)1.f;
+    col[13] = col[14] = col[15] = (_Float16)0.f;
+    const int64_t pair = row >> 5;
+    const int kk = (int)(row & 31), th = kk >> 4, kt = kk & 15, g = kt >> 2, r = kt & 3;
+    _Float16* dst = reinterpret_cast<_Float16*>(vp + (pair * 4 + g) * 16) + 4 * th + r;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * 8] = col[j];
+}
+
+__global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
+                                                                const uint4* __restrict__ vp, int B, int L, int H,
+                                                                float* __restrict__ out) {
+    __shared__ AttnSmem4 sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqb = (L + 255) / 256;
+    const unsigned nwg = gridDim.x;
+    unsigned wg = blockIdx.x;
+    {   // XCD-aware renumbering (see v3)
+        const unsigned q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int qblk = wg % nqb;
+    const int h = (wg / nqb) % H, b = wg / (nqb * H);
+    const int64_t M = (int64_t)B * L;
+    const int64_t base = ((int64_t)h * M + (int64_t)b * L) * 4;
+    const float* qh = q + base;
+    const uint4* kph = kp + ((int64_t)h * M + (int64_t)b * L) * 2;        // 2 uint4 per key
+    const uint4* vph = vp + (((int64_t)h * M + (int64_t)b * L) >> 5) * 64; // 64 uint4 per 32-key pair-tile
+    const int li = lane & 15, lg = lane >> 4;
+    const int q0 = qblk * 256 + wave * 64;
+
+    if (tid < 16) sm.ones[tid] = (tid == 0 || tid == 1) ? make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+
+    const float qscale = 0.5f * 1.4426950408889634f;
+    uint4 qfrag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qi = q0 + 16 * j + li;
+        qi = qi < L ? qi : L - 1;
+        const float4 qv = *reinterpret_cast<const float4*>(qh + (int64_t)qi * 4);
+        const float qs[4] = {qv.x * qscale, qv.y * qscale, qv.z * qscale, qv.w * qscale};
+        uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split3(qs[d], q1[d], q2[d], q3[d]);
+        const uint4 f0 = pack8(q1, q1), f1 = pack8(q2, q2), f2 = pack8(q1, q3);
+        qfrag[j] = lg == 0 ? f0 : (lg == 1 ? f1 : (lg == 2 ? f2 : make_uint4(0u, 0u, 0u, 0u)));
+    }
+
+    const int nchunks = (L + KC - 1) / KC;
+    // chunk staging = plain copy of the pre-split images: K 512 uint4 + V 512 uint4 per 256-key chunk
+    uint4 rk0, rk1, rv0, rv1;
+    auto load_chunk = [&](int c) {
+        const int keys = min(KC, L - c * KC);                     // multiple of 32
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const uint4* ksrc = kph + (int64_t)c * KC * 2;
+        const uint4* vsrc = vph + (int64_t)c * (KC / 32) * 64;
+        rk0 = tid < keys * 2 ? ksrc[tid] : z;
+        rk1 = tid + 256 < keys * 2 ? ksrc[tid + 256] : z;
+        rv0 = tid < keys * 2 ? vsrc[tid] : z;
+        rv1 = tid + 256 < keys * 2 ? vsrc[tid + 256] : z;
+    };
+    auto store_chunk = [&](int buf, int) {
+        uint4* kd = &sm.k[buf][0][0];
+        uint4* vd = &sm.v[buf][0][0][0];
+        kd[tid] = rk0; kd[tid + 256] = rk1;
+        vd[tid] = rv0; vd[tid + 256] = rv1;
+    };
+
+    f32x4 acc[4], sav[4];
+    float mq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mq[j] = 0.f;
+        acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    const int slot = ((lg >> 1) ^ (li >> 3)) & 1;
+    const uint4* kbase0 = (lg == 3) ? &sm.ones[(li >= 4 && li < 12) ? 0 : 1] : &sm.k[0][li][slot];
+    const int kstep = (lg == 3) ? 0 : 32;
+    const int kbuf = (lg == 3) ? 0 : KC * 2;
+    {   // m = ceil(max over the first 64 keys) - 3, shared by the 4 key groups of a query
+        const int nt0 = min(4, L >> 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m0 = -INFINITY;
+            for (int t = 0; t < nt0; ++t) {
+                const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kbase0[t * kstep]), as_frag(qfrag[j]), zero, 0, 0, 0);
+                m0 = fmaxf(m0, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 16));
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            mq[j] = ceilf(m0) - 3.f;
+            if (lg == 3) qfrag[j] = negm_frag(mq[j]);
+        }
+    }
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const int npairs = min(KC, L - c * KC) >> 5;
+        const uint4* kb = kbase0 + buf * kbuf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sav[j] = acc[j];
+        for (int attempt = 0; attempt < 16; ++attempt) {
+            for (int u = 0; u < npairs; ++u) {
+                const bf16x8 kf0 = as_frag(kb[(2 * u) * kstep]);
+                const bf16x8 kf1 = as_frag(kb[(2 * u + 1) * kstep]);
+                const f16x8 vb = as_h8(sm.v[buf][u][lg][li]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, as_frag(qfrag[j]), zero, 0, 0, 0);
+                    const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, as_frag(qfrag[j]), zero, 0, 0, 0);
+                    float p[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(s0[r]); p[4 + r] = __builtin_amdgcn_exp2f(s1[r]); }
+                    uint4 hi, lo;
+                    split_p8(p, hi, lo);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
+                }
+            }
+            // overflow screen (f16 hi part saturated to inf somewhere in this chunk): rare
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad = bad || !(fabsf(acc[j][r]) < 3.0e38f);
+            if (!__any(bad)) break;
+            // rare path: exact maximum of this chunk's scores per query (relative to the current m), then move m so that
+            // the chunk maximum lands in (2^2, 2^3]; accumulators restart from the chunk-start copy scaled by 2^-delta.
+            float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int t = 0; t < 2 * npairs; ++t) {
+                const bf16x8 kf = as_frag(kb[t * kstep]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 sx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, as_frag(qfrag[j]), zero, 0, 0, 0);
+                    cmax[j] = fmaxf(cmax[j], fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3])));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float cm = fmaxf(cmax[j], __shfl_xor(cmax[j], 16));        // lane (query li): max over the 4 key groups
+                cm = fmaxf(cm, __shfl_xor(cm, 32));
+                const float delta = cm >= 15.f ? ceilf(cm) - 3.f : 0.f;      // integer; only queries that can overflow
+                mq[j] += delta;
+                if (lg == 3) qfrag[j] = negm_frag(mq[j]);
+                // accumulator rows of this lane are queries 4*lg + r: fetch their delta from the lane holding that query
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dr = __shfl(delta, (lane & 48) + 4 * lg + r);
+                    acc[j][r] = sav[j][r] * __builtin_amdgcn_exp2f(-dr);
+                }
+                sav[j] = acc[j];
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1, c + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[query][col], col on the lane (l&15): out_d = D[d] + D[4+d]/2^11 + D[8+d]/2^22, row sum = D[12]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = acc[j][r];
+            const int rowbase = lane & 48;
+            const float a1 = __shfl(a, rowbase + (li & 3) + 4);
+            const float a2 = __shfl(a, rowbase + (li & 3) + 8);
+            const float l = __shfl(a, rowbase + 12);
+            const int qi = q0 + 16 * j + 4 * lg + r;
+            if (li < 4 && qi < L) {
+                const float o = (a + a1 * 0.00048828125f + a2 * 2.384185791015625e-07f) / l;
+                out[((int64_t)b * L + qi) * (H * 4) + h * 4 + li] = o;
+            }
+        }
+    }
+}
+
 // General cross-attention with Te condition tokens (tiny: Te <= 77), one thread per (row, head).
 __global__ void d3pm_cross_attention_kernel(const float* q, const float* kc, const float* vc, int B, int L, int Te, int H,
                                             float* out) {
@@ -291,13 +572,29 @@ __global__ void d3pm_cross_attention_kernel(const float* q, const float* kc, con
 
 using namespace gsdd;
 
+extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
+    return (int64_t)B * L * H * 64;          // 32 B (K pieces) + 32 B (V image) per key and head
+}
+
 extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
-                                   void* stream) {
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     GSDD_CHECK_ARG(q && k && v && out, "null pointer");
     GSDD_CHECK_ARG(B > 0 && H > 0 && L >= 16 && L % 16 == 0, "L must be a positive multiple of 16");
-    GSDD_CHECK_ARG(B <= 65535 && H <= 65535, "grid too large");
-    const dim3 grid((L + 255) / 256, H, B);
-    hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, B, L, H, out);
+    GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
+    const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
+    static const bool force_v3 = getenv("GSDD_ATTN_V3") != nullptr;    // A/B switch: exact-f32 P.V (mfma 4x4x1) variant
+    hipStream_t st = (hipStream_t)stream;
+    if (L % 32 == 0 && !force_v3 && workspace != nullptr) {
+        GSDD_CHECK_ARG(workspace_bytes >= gsdd_d3pm_attention_workspace_bytes(B, L, H), "workspace too small");
+        const int64_t rows = (int64_t)B * L * H;
+        uint4* kp = reinterpret_cast<uint4*>(workspace);
+        uint4* vp = kp + rows * 2;
+        hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
+        GSDD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(d3pm_attention_v4_kernel, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out);
+    } else {
+        hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);
+    }
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -187,7 +187,7 @@ class Text2ImageTransformer(nn.Module):
                        ln=(stats, layers[0]["ada1"].view(-1), layers[0]["ada1"].view(-1)[D:], t2, 2 * D),
                        rows_per_batch=L, out_mode=2, stream=stream)
             for li, lay in enumerate(layers):
-                ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, stream=stream)
+                ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), stream=stream)
                 nxt = layers[li + 1] if li + 1 < len(layers) else None
                 ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, stream=stream)
         else:
@@ -205,7 +205,7 @@ class Text2ImageTransformer(nn.Module):
             ops.linear(x, lay["wqkv"], qkv, bias=lay["bqkv"],
                        ln=(stats, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t2, 2 * D),
                        rows_per_batch=L, out_mode=2, stream=stream)
-            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, stream=stream)
+            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), stream=stream)
             if Te == 1:
                 ops.linear(y, lay["wproj"], x, bias=lay["bproj"], bvec=condv[li], rows_per_batch=L, residual=x,
                            stream=stream)
@@ -231,7 +231,7 @@ class Text2ImageTransformer(nn.Module):
         return {"x": torch.empty((M, D), **f), "stats": torch.empty((M, 2), **f),
                 "qkv": torch.empty((3 * H, M, 4), **f), "y": torch.empty((M, D), **f),
                 "h": torch.empty((M, self.blocks[0].mlp[0].out_features), **f),
-                "logits": torch.empty((M, K), **f)}
+                "logits": torch.empty((M, K), **f), "attn": ops.d3pm_attention_workspace(B2, L, H, device)}
 
     @torch.no_grad()
     def forward(self, input, cond_emb, t):

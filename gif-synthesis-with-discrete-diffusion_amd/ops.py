@@ -112,8 +112,15 @@ def small_linear(x, w, b, out=None, stream=None):
     return out
 
 
-def d3pm_attention(q, k, v, B, L, H, out, stream=None):
-    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), stream_ptr(stream)))
+def d3pm_attention_workspace(B, L, H, device):
+    n = lib().gsdd_d3pm_attention_workspace_bytes(B, L, H)
+    return torch.empty((n // 4,), dtype=torch.float32, device=device)
+
+
+def d3pm_attention(q, k, v, B, L, H, out, ws=None, stream=None):
+    """ws: scratch from d3pm_attention_workspace (matrix-pipe kernel); None -> workspace-free exact-f32 P.V kernel."""
+    nbytes = 0 if ws is None else ws.numel() * 4
+    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(ws), nbytes, stream_ptr(stream)))
     return out
 
 

@@ -115,8 +115,11 @@ int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const floa
 /* Self-attention for head dim 4: q,k,v head-major [H][M][4] (M = B*L rows), out rows [M][H*4].
  * softmax(q k^T / sqrt(4)) v, scores never leave registers.
  * Replaces FullAttention.forward: transformer_utils.py:46-62 (head-mean att is dropped: unused). */
+/* workspace: gsdd_d3pm_attention_workspace_bytes(B,L,H) bytes of scratch for the pre-split K/V images of the
+ * matrix-pipe kernel; NULL selects the workspace-free kernel (exact-f32 P.V on v_mfma_f32_4x4x1). */
+int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H);
 int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
-                        float* out, void* stream);
+                        float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused post-attention half of a denoiser block (n_embd 64, hidden 256), rows updated in place:
  *   x += proj(y)+b_proj+cvec[b];  x += W2 GELU2(W1 LN2(x)+b1)+b2;  [qkv_next = Wqkv AdaLN_next(x,t)+b_qkv, head-major]

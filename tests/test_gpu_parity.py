@@ -225,8 +225,9 @@ def attention_ref(q, k, v):
     return (att @ v.double())
 
 
-@pytest.mark.parametrize("B,L,spike", [(2, 64, False), (1, 1024, False), (2, 4096, False), (1, 512, True)])
-def test_d3pm_attention(G, B, L, spike):
+@pytest.mark.parametrize("use_ws", [True, False])
+@pytest.mark.parametrize("B,L,spike", [(2, 64, False), (1, 1024, False), (2, 4096, False), (1, 512, True), (1, 48, False)])
+def test_d3pm_attention(G, B, L, spike, use_ws):
     H = 16
     g = torch.Generator().manual_seed(5)
     q = torch.randn(B, H, L, 4, generator=g) * 1.5
@@ -238,7 +239,8 @@ def test_d3pm_attention(G, B, L, spike):
     want = attention_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, H * 4)
     hm = lambda z: dev(z.permute(1, 0, 2, 3).reshape(H, B * L, 4).contiguous())
     out = torch.empty((B * L, H * 4), device="cuda")
-    G.ops.d3pm_attention(hm(q), hm(k), hm(v), B, L, H, out)
+    ws = G.ops.d3pm_attention_workspace(B, L, H, "cuda") if use_ws else None   # matrix-pipe kernel / exact-f32 P.V kernel
+    G.ops.d3pm_attention(hm(q), hm(k), hm(v), B, L, H, out, ws=ws)
     err = (out.cpu().double() - want).abs().max().item()
     assert err < 2e-5, err
 

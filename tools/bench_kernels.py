@@ -30,7 +30,8 @@ def main():
     if "attn" in which:
         q = torch.randn((3 * H, M, 4), device=dev)
         out = torch.empty((M, H * 4), device=dev)
-        ms = timeit(lambda: ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out))
+        aws = ops.d3pm_attention_workspace(B2, L, H, dev)
+        ms = timeit(lambda: ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, ws=aws))
         fl = 16.0 * L * L * H * B2
         print(f"attention  B2={B2} L={L}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
     if "gemm" in which:

@@ -21,6 +21,8 @@ __global__ void k(float* out, long long* t0s, long long* t1s) {
     f32x4 s[4];
     for (int j = 0; j < 4; ++j) s[j] = f32x4{-1.f - j, -2.f, -3.f, -4.f};
     float guard = 0.f;
+    float pp[4][4];
+    for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) pp[j][r] = 0.5f + j + r;
     __syncthreads();
     long long t0 = clock64();
     for (int it = 0; it < N_IT; ++it) {
@@ -42,7 +44,53 @@ __global__ void k(float* out, long long* t0s, long long* t1s) {
             for (int j = 0; j < 4; ++j) { mx = fmaxf(fmaxf(mx, s[j][0]), s[j][1]); mx = fmaxf(fmaxf(mx, s[j][2]), s[j][3]); }
             if (__any(mx > 40.f)) guard += 1.f;
         }
-        if (MODE >= 1) {
+        if (MODE == 8 || MODE == 9) {
+            float p[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[j][r] = __builtin_amdgcn_exp2f(s[j][r]);
+            if (MODE == 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_fmaf(p[j][r], vb[(r + e) & 3], acc[j][e]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ls[j] += (p[j][0] + p[j][1]) + (p[j][2] + p[j][3]);
+            } else {   // MODE 9: exp only + sums (no PV, no QK dependence)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ls[j] += (p[j][0] + p[j][1]) + (p[j][2] + p[j][3]);
+            }
+        } else if (MODE == 6 || MODE == 7) {
+            // software pipelined: PV MFMAs consume the previous tile's p while this tile's exps are issued
+            float p[4][4];
+            if (MODE == 6) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        p[j][r] = __builtin_amdgcn_exp2f(s[j][r]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(pp[j][r], vb[r], acc[j], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p[j][r] = __builtin_amdgcn_exp2f(s[j][r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(pp[j][r], vb[r], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ls[j] += (p[j][0] + p[j][1]) + (p[j][2] + p[j][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pp[j][r] = p[j][r];
+        } else if (MODE >= 1) {
             float p[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -60,7 +108,7 @@ __global__ void k(float* out, long long* t0s, long long* t1s) {
     }
     long long t1 = clock64();
     float r = ls[0] + ls[1] + ls[2] + ls[3] + guard;
-    for (int j = 0; j < 4; ++j) r += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    for (int j = 0; j < 4; ++j) r += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3] + pp[j][0] + pp[j][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) { t0s[threadIdx.x >> 6] = t0; t1s[threadIdx.x >> 6] = t1; }
 }
@@ -84,5 +132,9 @@ int main() {
     run<3>("M3 = M2 + max check");
     run<4>("M4 4 bf16 mfma + 16 exp + sums (no PV)");
     run<5>("M5 = M4 + max check");
+    run<8>("M8 4 bf16 mfma + 16 exp + 64 v_fma + sums");
+    run<9>("M9 4 bf16 mfma + 16 exp + sums");
+    run<6>("M6 M2 software-pipelined, exp/mfma interleaved");
+    run<7>("M7 M2 software-pipelined, 16 exp then 16 mfma");
     return 0;
 }
