@@ -13,7 +13,7 @@ _lib = None
 EXPORTS = [
     "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
     "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
-    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_advance",
+    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
     "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
 ]
@@ -79,6 +79,7 @@ def lib():
         L.gsdd_d3pm_attention_workspace_bytes.argtypes = [_i, _i, _i]
         L.gsdd_d3pm_attention_workspace_bytes.restype = _i64
         L.gsdd_d3pm_layer.argtypes = [C.POINTER(LayerDesc), _p]
+        L.gsdd_d3pm_logits.argtypes = [_p, _i64, _i, _p, _p, _p, _p, _i, _p, _p]
         L.gsdd_d3pm_cross_attention.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p]
         L.gsdd_d3pm_step.argtypes = [C.POINTER(StepDesc), _p]
         L.gsdd_d3pm_q_sample.argtypes = [_p, _p, _i, _i, _i, _i, C.POINTER(_p), _p, C.c_uint64, _p, _i64, _p]

@@ -232,6 +232,96 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// to_logits: logits[m][:] = W LN(x[m]) + b  (nn.LayerNorm(64) + nn.Linear(64 -> K), transformer_utils.py:353-356,442).
+// Same transposed-GEMM register layout: a wave owns 32 rows, normalises them in registers once and sweeps all K
+// output features; W streams through LDS in 256-feature chunks shared by the 8 waves (double-buffered).
+struct LogitsArgs {
+    const float* x; int64_t M; int K;
+    const float* g; const float* b;      // LayerNorm affine
+    const float* w; const float* bias;   // [K][64], [K]
+    float* out;                          // [M][K]
+};
+
+constexpr int LCH = 256;                 // features per LDS chunk
+
+__global__ __launch_bounds__(512, 1) void d3pm_logits_kernel(const LogitsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][LCH][W1P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int nch = (a.K + LCH - 1) / LCH;
+    const int64_t nblocks = (a.M + 255) / 256;
+
+    float4 stage[8];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 512 * i;               // 4096 float4 per chunk
+            const int n = c * LCH + (idx >> 4), col = (idx & 15) * 4;
+            stage[i] = n < a.K ? *reinterpret_cast<const float4*>(a.w + (int64_t)n * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 512 * i;
+            *reinterpret_cast<float4*>(&lds[(buf * LCH + (idx >> 4)) * W1P + (idx & 15) * 4]) = stage[i];
+        }
+    };
+
+    for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int64_t m = blk * 256 + wave * 32 + li;
+        const bool valid = m < a.M;
+        const int64_t mc = valid ? m : a.M - 1;
+        float xr[32], act[32];
+        load_frag(a.x + mc * D, h, xr);
+        float mean, rstd;
+        row_norm(xr, mean, rstd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 gm = *reinterpret_cast<const float4*>(a.g + f);
+                const float4 bt = *reinterpret_cast<const float4*>(a.b + f);
+                const int r = 16 * t + 4 * g;
+                act[r + 0] = (xr[r + 0] - mean) * rstd * gm.x + bt.x;
+                act[r + 1] = (xr[r + 1] - mean) * rstd * gm.y + bt.y;
+                act[r + 2] = (xr[r + 2] - mean) * rstd * gm.z + bt.z;
+                act[r + 3] = (xr[r + 3] - mean) * rstd * gm.w + bt.w;
+            }
+        __syncthreads();                 // previous block's readers are done with both buffers
+        load_w(0);
+        store_w(0);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nch) load_w(c + 1);
+            const float* wl = lds + buf * LCH * W1P;
+#pragma unroll 1
+            for (int sc = 0; sc < LCH / 64; ++sc) {
+                f32x16 acc[2];
+                zero2(acc);
+                gemm64<true>(wl + sc * 64 * W1P, W1P, 0, li, h, act, acc);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = c * LCH + sc * 64 + 32 * t + 8 * g + 4 * h;
+                        if (valid && n < a.K) {
+                            const float4 bb = *reinterpret_cast<const float4*>(a.bias + n);
+                            const int r = 4 * g;
+                            *reinterpret_cast<float4*>(a.out + m * a.K + n) =
+                                make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
+                        }
+                    }
+            }
+            if (c + 1 < nch) store_w(buf ^ 1);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
@@ -260,6 +350,24 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     }
     if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_d3pm_logits(const float* x, int64_t M, int n_embd, const float* ln_g, const float* ln_b, const float* w,
+                                const float* bias, int K, float* out, void* stream) {
+    GSDD_CHECK_ARG(x && ln_g && ln_b && w && bias && out, "null pointer");
+    GSDD_CHECK_ARG(M > 0 && n_embd == 64 && K > 0 && K % 4 == 0, "kernel is specialised for n_embd 64, K % 4 == 0");
+    LogitsArgs a;
+    a.x = x; a.M = M; a.K = K; a.g = ln_g; a.b = ln_b; a.w = w; a.bias = bias; a.out = out;
+    const size_t lds = (size_t)2 * LCH * W1P * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>((M + 255) / 256, 256);
+    hipLaunchKernelGGL(d3pm_logits_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -192,8 +192,11 @@ class Text2ImageTransformer(nn.Module):
                 ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, stream=stream)
         else:
             self._run_blocks_unfused(layers, condv, Te, t2, ws, B2, L, stream)
-        ops.row_stats(x, stats, stream=stream)
-        ops.linear(x, p["wl"], logits, bias=p["bl"], ln=(stats, p["gf"], p["bf"], None, 0), stream=stream)
+        if D == 64 and p["wl"].shape[0] % 4 == 0:
+            ops.d3pm_logits(x, p["gf"], p["bf"], p["wl"], p["bl"], logits, stream=stream)
+        else:
+            ops.row_stats(x, stats, stream=stream)
+            ops.linear(x, p["wl"], logits, bias=p["bl"], ln=(stats, p["gf"], p["bf"], None, 0), stream=stream)
         return logits
 
     def _run_blocks_unfused(self, layers, condv, Te, t2, ws, B2, L, stream):

@@ -136,6 +136,12 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, stream=None
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
 
 
+def d3pm_logits(x, g, b, w, bias, out, stream=None):
+    check(lib().gsdd_d3pm_logits(ptr(x), x.shape[0], x.shape[1], ptr(g), ptr(b), ptr(w), ptr(bias), w.shape[0], ptr(out),
+                                 stream_ptr(stream)))
+    return out
+
+
 def d3pm_cross_attention(q, kc, vc, B, L, Te, H, out, stream=None):
     check(lib().gsdd_d3pm_cross_attention(ptr(q), ptr(kc), ptr(vc), B, L, Te, H, ptr(out), stream_ptr(stream)))
     return out

@@ -144,6 +144,11 @@ typedef struct {
 } gsdd_layer_desc;
 int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
 
+/* to_logits: out[m][:] = W LayerNorm(x[m]) + bias  (nn.LayerNorm + nn.Linear, transformer_utils.py:353-356, 442);
+ * x: [M][64], w: [K][64], out: [M][K] rows (the reference's (B,K,L) is a transposed view of this). */
+int gsdd_d3pm_logits(const float* x, int64_t M, int n_embd, const float* ln_g, const float* ln_b, const float* w,
+                     const float* bias, int K, float* out, void* stream);
+
 /* General cross-attention (T_E condition tokens), head dim 4; q head-major [H][M][4],
  * kc/vc rows [B*Te][H*4]; out rows [M][H*4].  transformer_utils.py:95-113. */
 int gsdd_d3pm_cross_attention(const float* q, const float* kc, const float* vc, int B, int L, int Te,

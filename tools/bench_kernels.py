@@ -23,7 +23,7 @@ def timeit(fn, iters=10, warm=2):
 
 
 def main():
-    which = sys.argv[1:] or ["attn", "gemm", "layer", "step"]
+    which = sys.argv[1:] or ["attn", "gemm", "layer", "logits", "step"]
     dev = "cuda"
     B2, L, H, D, K = 32, 4096, 16, 64, 4096
     M = B2 * L
@@ -70,6 +70,13 @@ def main():
         ms = timeit(lambda: ops.d3pm_layer(y, x, L, p["layers"][0], cvec=cv))
         fl = 2.0 * M * (64 * 64 + 2 * 64 * 256)
         print(f"fused layer (proj+mlp, last):    {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+    if "logits" in which:
+        x = torch.randn((M, D), device=dev)
+        w = torch.randn((K, D), device=dev) * 0.05
+        b = torch.randn((K,), device=dev); g = torch.randn((D,), device=dev); bt = torch.randn((D,), device=dev)
+        o = torch.empty((M, K), device=dev)
+        ms = timeit(lambda: ops.d3pm_logits(x, g, bt, w, b, o))
+        print(f"logits kernel 64->{K}: {ms:.3f} ms  {2.0 * M * D * K / ms / 1e9:.1f} TFLOP/s  {4.0 * M * K / ms / 1e6:.0f} GB/s written")
     if "step" in which:
         Bs = B2 // 2
         logits = torch.randn((M, K), device=dev)
