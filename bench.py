@@ -113,10 +113,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("GSDD_DIST_BACKEND", "nccl")          # "gloo" only to rehearse N>1 on a 1-GPU box
+    if os.environ.get("GSDD_FORCE_DEVICE") is not None:
+        local = int(os.environ["GSDD_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
@@ -151,7 +154,7 @@ def main():
     assert torch.isfinite(clips).all()
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 

@@ -13,7 +13,7 @@ _lib = None
 EXPORTS = [
     "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
     "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
-    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_advance",
+    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
     "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
 ]
@@ -43,6 +43,16 @@ class StepDesc(C.Structure):
         ("B", _i), ("L", _i), ("K", _i), ("T", _i), ("guidance", C.c_float),
         ("sched", _p * 8), ("t_dev", _p), ("seed", C.c_uint64), ("stream_dev", _p), ("row0", _i64),
         ("post_dbg", _p), ("x0_dbg", _p),
+    ]
+
+
+class TrainDesc(C.Structure):
+    _fields_ = [
+        ("logits", _p), ("x0", _p), ("xt", _p), ("t_dev", _p), ("pt", _p),
+        ("B", _i), ("L", _i), ("K", _i), ("T", _i), ("sched", _p * 8), ("mask_weight", C.c_float * 2),
+        ("aux_weight", C.c_float), ("adaptive_aux", _i),
+        ("kl", _p), ("nll", _p), ("aux", _p), ("x0_recon", _p), ("xt1_recon", _p),
+        ("Lt_history", _p), ("Lt_count", _p), ("loss", _p), ("per_sample", _p), ("probs", _p),
     ]
 
 
@@ -83,6 +93,7 @@ def lib():
         L.gsdd_d3pm_cross_attention.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p]
         L.gsdd_d3pm_step.argtypes = [C.POINTER(StepDesc), _p]
         L.gsdd_d3pm_q_sample.argtypes = [_p, _p, _i, _i, _i, _i, C.POINTER(_p), _p, C.c_uint64, _p, _i64, _p]
+        L.gsdd_d3pm_train_loss.argtypes = [C.POINTER(TrainDesc), _p]
         L.gsdd_advance.argtypes = [_p, _i, _i64, _p, _i64, _p]
         L.gsdd_philox_uniform.argtypes = [C.c_uint64, _i64, _i64, _i64, _i, _p, _p]
         L.gsdd_graph_begin.argtypes = [_p]

@@ -265,6 +265,204 @@ __global__ void philox_uniform_kernel(uint64_t seed, uint32_t stream_id, int64_t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Training objective, forward value (diffusion_transformer.py:391-457): per position
+//   log_x0_recon = predict_start(logits)                      (:231-236)
+//   log_model    = q_posterior(log_x0_recon, onehot(x_t), t)   (:251-283)
+//   log_true     = q_posterior(onehot(x_0),  onehot(x_t), t)
+//   kl = sum_k exp(log_true)(log_true - log_model) ; nll = -sum_k exp(onehot(x_0)) log_model ;
+//   kl_aux = sum_{k<K} exp(onehot(x_0)) (onehot(x_0) - log_x0_recon)
+// written per position; x0_recon / x_{t-1}-recon arg-max tokens for pred_data and the acc/keep statistics.
+struct TrainArgs {
+    const float* logits;      // [B*L][K]
+    const int64_t* x0;
+    const int64_t* xt;
+    const int64_t* t_dev;
+    int B, L, K, T;
+    float mw_mask, mw_other;  // mask_weight
+    float* kl; float* nll; float* aux;       // [B*L]
+    int64_t* x0_recon; int64_t* xt1_recon;   // [B*L]
+    float* probs;             // optional [B][K+1][L] = exp(log_model)
+};
+
+template <int J>
+__global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, SchedPtrs sp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= (int64_t)d.B * d.L) return;
+    const int b = (int)(pos / d.L), l = (int)(pos % d.L);
+    const int K = d.K;
+    const float NEG = -INFINITY;
+    float xr[J][4];
+    const float* row = d.logits + pos * (int64_t)K;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = 4 * lane + 256 * j;
+        if (k < K) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            xr[j][0] = v.x; xr[j][1] = v.y; xr[j][2] = v.z; xr[j][3] = v.w;
+        } else {
+            xr[j][0] = xr[j][1] = xr[j][2] = xr[j][3] = NEG;
+        }
+    }
+    log_softmax_clamp<J>(xr);                       // log_x0_recon rows k < K; row K is -70
+    const int64_t t = d.t_dev[b];
+    const StepSched s = load_sched(sp.p, t, d.T);
+    const int64_t xt = d.xt[pos], x0 = d.x0[pos];
+    const bool masked = (xt == K);
+    const float qt_hit = lae(0.f + s.lca, s.lcb), qt_miss = lae(LOG_ZERO + s.lca, s.lcb);
+    const float q1_hit = lae(0.f + s.la, s.lb), q1_miss = lae(LOG_ZERO + s.la, s.lb);
+    // pass 1: the two normalisers S_m (model) and S_t (true)
+    float qm[J][4];
+    float mxm = LOG_ZERO, mxt = LOG_ZERO;            // include the [MASK] row (= LOG_ZERO) in both maxima
+    float best0 = NEG; int best0_k = 0;              // arg-max of log_x0_recon (row K = -70 competes)
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+            if (k < K) {
+                if (xr[j][e] > best0) { best0 = xr[j][e]; best0_k = k; }
+                qm[j][e] = xr[j][e] - log_qt;
+                mxm = fmaxf(mxm, qm[j][e]);
+                mxt = fmaxf(mxt, (k == x0 ? 0.f : LOG_ZERO) - log_qt);
+            } else {
+                qm[j][e] = NEG;
+            }
+        }
+    {   // row K of log_x0_recon is -70: first-max rule across the whole wave handled by wave_argmax (lowest index wins ties)
+        if (lane == 0 && -70.f > best0) { best0 = -70.f; best0_k = K; }
+    }
+    const int x0rec = wave_argmax(best0, best0_k);
+    mxm = wave_max(mxm); mxt = wave_max(mxt);
+    float sem = 0.f, set = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            if (k < K) {
+                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+                sem += expf(qm[j][e] - mxm);
+                set += expf(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
+            }
+        }
+    sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
+    set = wave_sum(set) + expf(LOG_ZERO - mxt);
+    const float Sm = mxm + logf(sem), St = mxt + logf(set);
+    // pass 2: posteriors, KL / NLL / aux partial sums, arg-max of log_model
+    float kl = 0.f, nll = 0.f, aux = 0.f;
+    float bestm = NEG; int bestm_k = 0;
+    const float E30 = expf(LOG_ZERO);               // exp(log-onehot "zero") as the reference computes it
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            if (k < K) {
+                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+                const float log_q1 = masked ? s.lc : (k == xt ? q1_hit : q1_miss);
+                const float lm = clamp70(lae((qm[j][e] - Sm) + s.pca, s.pcb) + log_q1 + Sm);
+                const float lx0 = (k == x0 ? 0.f : LOG_ZERO);
+                const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
+                kl += expf(ltr) * (ltr - lm);
+                const float w0 = (k == x0 ? 1.f : E30);
+                nll += w0 * lm;
+                aux += w0 * (lx0 - xr[j][e]);
+                if (lm > bestm) { bestm = lm; bestm_k = k; }
+                if (d.probs != nullptr) d.probs[((int64_t)b * (K + 1) + k) * d.L + l] = expf(lm);
+            }
+        }
+    kl = wave_sum(kl); nll = wave_sum(nll); aux = wave_sum(aux);
+    {   // the [MASK] class row
+        const float log_q1K = masked ? 0.f : LOG_ZERO;
+        const float lmK = clamp70(lae((LOG_ZERO - Sm) + s.p1mcc, s.pcc) + log_q1K + Sm);
+        const float ltK = clamp70(lae((LOG_ZERO - St) + s.p1mcc, s.pcc) + log_q1K + St);
+        kl += expf(ltK) * (ltK - lmK);
+        nll += (x0 == K ? 1.f : E30) * lmK;
+        if (lane == 0) {
+            if (lmK > bestm) { bestm = lmK; bestm_k = K; }
+            if (d.probs != nullptr) d.probs[((int64_t)b * (K + 1) + K) * d.L + l] = expf(lmK);
+        }
+    }
+    const int xt1 = wave_argmax(bestm, bestm_k);
+    if (lane == 0) {
+        const float mw = masked ? d.mw_mask : d.mw_other;
+        d.kl[pos] = kl * mw;
+        d.nll[pos] = -nll;
+        d.aux[pos] = aux * mw;
+        d.x0_recon[pos] = x0rec;
+        d.xt1_recon[pos] = xt1;
+    }
+}
+
+// per-sample reductions + the scalar tail of _train_loss / forward (:425-457, :548): one workgroup
+struct TrainFinArgs {
+    const float* kl; const float* nll; const float* aux;
+    const int64_t* x0; const int64_t* xt; const int64_t* x0_recon; const int64_t* xt1_recon;
+    const int64_t* t_dev; const float* pt;
+    int B, L, T;
+    float aux_weight; int adaptive;
+    float* Lt_history; float* Lt_count;
+    float* loss;              // [1]
+    float* per_sample;        // [B][4]: kl_loss, vb_loss, acc rate, keep rate
+};
+
+__global__ __launch_bounds__(256) void d3pm_train_finalize_kernel(TrainFinArgs a) {
+    __shared__ float red[4][256];
+    __shared__ float vb_all[1024];
+    const int tid = threadIdx.x;
+    for (int b = 0; b < a.B; ++b) {
+        float kl = 0.f, nll = 0.f, aux = 0.f, same0 = 0.f, same1 = 0.f;
+        for (int l = tid; l < a.L; l += 256) {
+            const int64_t p = (int64_t)b * a.L + l;
+            kl += a.kl[p]; nll += a.nll[p]; aux += a.aux[p];
+            same0 += (a.x0_recon[p] == a.x0[p]) ? 1.f : 0.f;
+            same1 += (a.xt1_recon[p] == a.xt[p]) ? 1.f : 0.f;
+        }
+        float vals[5] = {kl, nll, aux, same0, same1};
+        float tot[5];
+        for (int q = 0; q < 5; ++q) {
+            red[0][tid] = vals[q];
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) red[0][tid] += red[0][tid + o];
+                __syncthreads();
+            }
+            tot[q] = red[0][0];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int64_t t = a.t_dev[b];
+            const float m0 = (t == 0) ? 1.f : 0.f;
+            const float kl_loss = m0 * tot[1] + (1.f - m0) * tot[0];
+            float vb = kl_loss / a.pt[b];
+            if (a.aux_weight != 0.f) {
+                const float kl_aux_loss = m0 * tot[1] + (1.f - m0) * tot[2];
+                const float w = a.adaptive ? ((1.f - (float)t / (float)a.T) + 1.0f) : 1.0f;
+                vb += w * a.aux_weight * kl_aux_loss / a.pt[b];
+            }
+            // Lt_history.scatter_(t, 0.1*Lt2 + 0.9*prev) ; Lt_count.scatter_add_(t, 1)   (:432-436; sample order)
+            const float lt2 = kl_loss * kl_loss;
+            a.Lt_history[t] = 0.1f * lt2 + 0.9f * a.Lt_history[t];
+            a.Lt_count[t] += 1.f;
+            a.per_sample[4 * b + 0] = kl_loss;
+            a.per_sample[4 * b + 1] = vb;
+            a.per_sample[4 * b + 2] = tot[3] / (float)a.L;
+            a.per_sample[4 * b + 3] = tot[4] / (float)a.L;
+            vb_all[b] = vb;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float sum = 0.f;
+        for (int b = 0; b < a.B; ++b) sum += vb_all[b];
+        a.loss[0] = sum / ((float)a.B * (float)a.L);
+    }
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
@@ -323,6 +521,42 @@ extern "C" int gsdd_philox_uniform(uint64_t seed, int64_t stream_id, int64_t row
     const int64_t n = n_rows * (int64_t)((n_cols + 3) / 4);
     hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        seed, (uint32_t)stream_id, row0, n_rows, n_cols, out);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_d3pm_train_loss(const gsdd_train_desc* d, void* stream) {
+    GSDD_CHECK_ARG(d != nullptr, "null descriptor");
+    GSDD_CHECK_ARG(d->logits && d->x0 && d->xt && d->t_dev && d->pt && d->kl && d->nll && d->aux && d->x0_recon &&
+                   d->xt1_recon && d->Lt_history && d->Lt_count && d->loss && d->per_sample, "null pointer");
+    GSDD_CHECK_ARG(d->B > 0 && d->B <= 1024 && d->L > 0 && d->T > 0, "bad sizes (B <= 1024)");
+    GSDD_CHECK_ARG(d->K >= 4 && d->K % 4 == 0 && d->K <= 8192, "K must be a multiple of 4 in [4, 8192]");
+    SchedPtrs sp;
+    for (int i = 0; i < 8; ++i) {
+        GSDD_CHECK_ARG(d->sched[i] != nullptr, "null schedule buffer");
+        sp.p[i] = d->sched[i];
+    }
+    TrainArgs a;
+    a.logits = d->logits; a.x0 = d->x0; a.xt = d->xt; a.t_dev = d->t_dev; a.B = d->B; a.L = d->L; a.K = d->K; a.T = d->T;
+    a.mw_mask = d->mask_weight[0]; a.mw_other = d->mask_weight[1];
+    a.kl = d->kl; a.nll = d->nll; a.aux = d->aux; a.x0_recon = d->x0_recon; a.xt1_recon = d->xt1_recon; a.probs = d->probs;
+    const int64_t npos = (int64_t)d->B * d->L;
+    const dim3 grid((unsigned)((npos + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int J = (d->K + 255) / 256;
+    if (J <= 1) hipLaunchKernelGGL(d3pm_train_loss_kernel<1>, grid, block, 0, st, a, sp);
+    else if (J <= 2) hipLaunchKernelGGL(d3pm_train_loss_kernel<2>, grid, block, 0, st, a, sp);
+    else if (J <= 4) hipLaunchKernelGGL(d3pm_train_loss_kernel<4>, grid, block, 0, st, a, sp);
+    else if (J <= 8) hipLaunchKernelGGL(d3pm_train_loss_kernel<8>, grid, block, 0, st, a, sp);
+    else if (J <= 16) hipLaunchKernelGGL(d3pm_train_loss_kernel<16>, grid, block, 0, st, a, sp);
+    else hipLaunchKernelGGL(d3pm_train_loss_kernel<32>, grid, block, 0, st, a, sp);
+    GSDD_CHECK_LAUNCH();
+    TrainFinArgs f;
+    f.kl = d->kl; f.nll = d->nll; f.aux = d->aux; f.x0 = d->x0; f.xt = d->xt; f.x0_recon = d->x0_recon;
+    f.xt1_recon = d->xt1_recon; f.t_dev = d->t_dev; f.pt = d->pt; f.B = d->B; f.L = d->L; f.T = d->T;
+    f.aux_weight = d->aux_weight; f.adaptive = d->adaptive_aux; f.Lt_history = d->Lt_history; f.Lt_count = d->Lt_count;
+    f.loss = d->loss; f.per_sample = d->per_sample;
+    hipLaunchKernelGGL(d3pm_train_finalize_kernel, dim3(1), dim3(256), 0, st, f);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

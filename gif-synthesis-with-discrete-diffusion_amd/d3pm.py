@@ -408,9 +408,70 @@ class DiffusionTransformer(nn.Module):
                       post_dbg=post_dbg, x0_dbg=x0_dbg)
         return out
 
+    # ------------------------------------------------------------------ training objective (forward value)
+    def sample_time(self, b, device, method="uniform"):
+        """diffusion_transformer.py:368-389 (host-side control flow; importance sampling once every Lt_count > 10)."""
+        if method == "importance":
+            if not (self.Lt_count > 10).all():
+                return self.sample_time(b, device, method="uniform")
+            Lt_sqrt = torch.sqrt(self.Lt_history + 1e-10) + 0.0001
+            Lt_sqrt[0] = Lt_sqrt[1]
+            pt_all = Lt_sqrt / Lt_sqrt.sum()
+            t = torch.multinomial(pt_all, num_samples=b, replacement=True)
+            return t, pt_all.gather(dim=0, index=t)
+        if method == "uniform":
+            t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+            return t, torch.ones_like(t).float() / self.num_timesteps
+        raise ValueError(method)
+
+    @torch.no_grad()
+    def _train_loss(self, x, cond_emb, is_train=True, want_probs=True):
+        """_train_loss (diffusion_transformer.py:391-457) as HIP kernels: q_sample -> denoiser -> fused KL/NLL/aux
+        reduction.  Forward value only: there is no backward on the HIP path yet, so nothing here records a graph."""
+        dev = x.device
+        B, L = x.shape
+        K, T = self.num_classes - 1, self.num_timesteps
+        t, pt = self.sample_time(B, dev, "importance")
+        t = t.to(dev).long().contiguous()
+        pt = pt.to(dev).float().contiguous()
+        sid = torch.tensor([self.noise_stream], dtype=torch.int64, device=dev)
+        self.noise_stream += 1
+        sched = self._sched()
+        x0 = x.contiguous().long()
+        xt = torch.empty_like(x0)
+        ops.d3pm_q_sample(x0, xt, sched, t, sid, K=K, T=T, seed=self.noise_seed, row0=self.row_offset * L)
+        tr = self.transformer
+        ws = tr.workspace(B, L, dev)
+        cond = cond_emb.float().contiguous()
+        logits = tr.run(xt, tr.cond_vectors(cond), cond.shape[1], t, ws)
+        aux_w = self.auxiliary_loss_weight if is_train else 0.0
+        out = ops.d3pm_train_loss(logits, x0, xt, t, pt, sched, self.Lt_history, self.Lt_count, K=K, T=T,
+                                  mask_weight=self.mask_weight, aux_weight=aux_w,
+                                  adaptive_aux=self.adaptive_auxiliary_loss, want_probs=want_probs)
+        out["t"], out["xt"] = t, xt
+        return out
+
     def forward(self, input, return_loss=False, return_logits=True, return_att_weight=False, is_train=True, **kwargs):
-        raise NotImplementedError("D3PM training loss (_train_loss, diffusion_transformer.py:391-457) is not built "
-                                  "yet on the HIP path")
+        """diffusion_transformer.py:520-565 -> {'logits': exp(log_model_prob) (B,K+1,L), 'loss', 'pred_data' (B,L)}."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.transformer.parameters()) and self.training:
+            raise NotImplementedError("the D3PM backward pass is not built on the HIP path yet: evaluate the training "
+                                      "objective under torch.no_grad() / .eval()")
+        tok = input["content_token"]
+        if not tok.is_cuda:
+            raise GsddError("the HIP path needs tensors on a ROCm device (no CPU fallback)")
+        cond = input.get("condition_embed_token")
+        if cond is None:
+            raise NotImplementedError("cond_emb=None is not used by the reference call sites")
+        out = {}
+        if is_train:
+            r = self._train_loss(tok, cond.float(), is_train=True, want_probs=return_logits)
+            if return_logits:
+                out["logits"] = r["probs"]
+            if return_loss:
+                out["loss"] = r["loss"][0]
+            out["pred_data"] = r["x0_recon"]
+            self.last_train_stats = r
+        return out
 
 
 class DiscreteDiffusion(nn.Module):
@@ -427,6 +488,24 @@ class DiscreteDiffusion(nn.Module):
             diffusion_model = instantiate(diffusion_model)
         self.textencoder = textencoder
         self.diffusion_model = diffusion_model
+
+    @torch.no_grad()
+    def forward(self, batch, autoencoder, length_estimator=None, do_inference=False):
+        """discrete_diffusion.py:16-83: encode -> diffusion objective -> [sample] -> decode; same output-dict keys.
+        (Forward values only; the reference also zeroes the text embeddings, :25 and :49.)"""
+        x = batch["video"].to(autoencoder.device)
+        quant = autoencoder.encode(x)
+        quant_flat = quant.view(x.shape[0], -1)
+        text_emb = torch.zeros_like(self.textencoder(batch["text"]).unsqueeze(1).to(autoencoder.device))
+        diffusion_out = self.diffusion_model({"condition_embed_token": text_emb, "content_token": quant_flat},
+                                             return_loss=True)
+        single_step_out = autoencoder.decode(diffusion_out["pred_data"].view(quant.shape).clamp(max=autoencoder.n_codes - 1))
+        test = autoencoder.decode(quant)
+        out = {"pred_data": single_step_out, "gt_data": x, "losses": diffusion_out["loss"], "test": test}
+        if do_inference:
+            out["pred_single_step"] = single_step_out
+            out["pred_data"] = self.sample_videos(batch["text"], autoencoder, latent_shape=tuple(quant.shape[1:]))
+        return out
 
     @torch.no_grad()
     def sample_videos(self, texts, autoencoder, latent_shape=None):

@@ -4,7 +4,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import GemmDesc, LayerDesc, StepDesc, check, lib, ptr, stream_ptr
+from ._lib import GemmDesc, LayerDesc, StepDesc, TrainDesc, check, lib, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_GELU2 = 0, 1, 2
 _keep = []          # tap tables are tiny device tensors that must outlive the launch
@@ -169,6 +169,32 @@ def d3pm_q_sample(x0, xt, sched, t_dev, stream_dev, *, K, T, seed, row0=0, strea
     check(lib().gsdd_d3pm_q_sample(ptr(x0), ptr(xt), B, L, K, T, arr, ptr(t_dev), seed, ptr(stream_dev), row0,
                                    stream_ptr(stream)))
     return xt
+
+
+def d3pm_train_loss(logits, x0, xt, t_dev, pt, sched, Lt_history, Lt_count, *, K, T, mask_weight, aux_weight, adaptive_aux,
+                    want_probs=True, stream=None):
+    """-> dict(loss [1], per_sample [B][4], x0_recon (B,L), xt1_recon (B,L), probs (B,K+1,L) or None)"""
+    B, L = x0.shape
+    dev = x0.device
+    f = dict(dtype=torch.float32, device=dev)
+    out = {"loss": torch.empty((1,), **f), "per_sample": torch.empty((B, 4), **f),
+           "x0_recon": torch.empty((B, L), dtype=torch.int64, device=dev),
+           "xt1_recon": torch.empty((B, L), dtype=torch.int64, device=dev),
+           "probs": torch.empty((B, K + 1, L), **f) if want_probs else None}
+    scratch = torch.empty((3, B * L), **f)
+    d = TrainDesc()
+    d.logits, d.x0, d.xt, d.t_dev, d.pt = ptr(logits), ptr(x0), ptr(xt), ptr(t_dev), ptr(pt)
+    d.B, d.L, d.K, d.T = B, L, K, T
+    for i in range(8):
+        d.sched[i] = ptr(sched[i])
+    d.mask_weight[0], d.mask_weight[1] = float(mask_weight[0]), float(mask_weight[1])
+    d.aux_weight, d.adaptive_aux = float(aux_weight), int(bool(adaptive_aux))
+    d.kl, d.nll, d.aux = ptr(scratch[0]), ptr(scratch[1]), ptr(scratch[2])
+    d.x0_recon, d.xt1_recon = ptr(out["x0_recon"]), ptr(out["xt1_recon"])
+    d.Lt_history, d.Lt_count = ptr(Lt_history), ptr(Lt_count)
+    d.loss, d.per_sample, d.probs = ptr(out["loss"]), ptr(out["per_sample"]), ptr(out["probs"])
+    check(lib().gsdd_d3pm_train_loss(C.byref(d), stream_ptr(stream)))
+    return out
 
 
 def advance(t_dev, dt, stream_dev, ds, stream=None):

@@ -186,6 +186,26 @@ int gsdd_d3pm_q_sample(const int64_t* x0, int64_t* xt, int B, int L, int K, int 
                        const float* const* sched, const int64_t* t_dev, uint64_t seed,
                        const int64_t* stream_dev, int64_t row0, void* stream);
 
+/* Training objective, forward value: _train_loss + the loss tail of forward (diffusion_transformer.py:391-457, :548)
+ * from the denoiser logits of x_t.  Per-position scratch (kl, nll, aux: float[B*L]; x0_recon, xt1_recon: int64[B*L]),
+ * per-sample results per_sample[B][4] = (kl_loss, vb_loss, acc rate, keep rate), loss[0] = sum(vb)/(B*L);
+ * Lt_history / Lt_count (float[T]) are updated in place (:432-436).  probs: optional [B][K+1][L] = exp(log_model_prob). */
+typedef struct {
+    const float* logits;        /* [B*L][K] denoiser output for x_t                         */
+    const int64_t* x0;          /* (B,L) clean tokens                                       */
+    const int64_t* xt;          /* (B,L) noised tokens (gsdd_d3pm_q_sample)                 */
+    const int64_t* t_dev;       /* int64[B]                                                 */
+    const float* pt;            /* float[B] sampling probability of t                       */
+    int B, L, K, T;
+    const float* sched[8];
+    float mask_weight[2];
+    float aux_weight; int adaptive_aux;
+    float* kl; float* nll; float* aux; int64_t* x0_recon; int64_t* xt1_recon;
+    float* Lt_history; float* Lt_count;
+    float* loss; float* per_sample; float* probs;
+} gsdd_train_desc;
+int gsdd_d3pm_train_loss(const gsdd_train_desc* d, void* stream);
+
 /* t[b] += dt ; stream[0] += ds   (device-side loop counters for the captured step graph) */
 int gsdd_advance(int64_t* t_dev, int B, int64_t dt, int64_t* stream_dev, int64_t ds, void* stream);
 
