@@ -12,7 +12,8 @@ _lib = None
 
 EXPORTS = [
     "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
-    "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
+    "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
+    "gsdd_codebook_ema", "gsdd_mse", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
     "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
     "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
@@ -82,6 +83,11 @@ def lib():
         L.gsdd_ncdhw_to_rows.argtypes = [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]
         L.gsdd_axial_attention.argtypes = [_p, _i, _i, _i, _i, _i, _i, _p, _p]
         L.gsdd_nearest_code.argtypes = [_p, _i64, _i, _p, _i, _p, _p, _p]
+        L.gsdd_bn_train_workspace_bytes.argtypes = [_i64, _i]
+        L.gsdd_bn_train_workspace_bytes.restype = _i64
+        L.gsdd_bn_train.argtypes = [_p, _i64, _i, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _p, _i64, _p]
+        L.gsdd_codebook_ema.argtypes = [_p, _p, _i64, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p, _i, _p]
+        L.gsdd_mse.argtypes = [_p, _p, _i64, C.c_float, _p, _p, _i64, _p]
         L.gsdd_d3pm_embed.argtypes = [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p]
         L.gsdd_adaln_table.argtypes = [_p, _i, _i, _p, _p, _p, _p]
         L.gsdd_small_linear.argtypes = [_p, _i, _i, _p, _p, _i, _p, _p]

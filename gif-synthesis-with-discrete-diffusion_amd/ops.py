@@ -89,6 +89,46 @@ def nearest_code(z, cb, idx, zq=None, stream=None):
     return idx
 
 
+def bn_train(x, bn, momentum=0.1, update_running=True, stream=None):
+    """Batch statistics of rows x[M][C] -> (scale, shift) for the consuming GEMM's prologue; updates bn's running stats."""
+    M, C_ = x.shape
+    n = lib().gsdd_bn_train_workspace_bytes(M, C_)
+    ws = torch.empty((n // 8,), dtype=torch.float64, device=x.device)
+    scale = torch.empty((C_,), dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    rm, rv = (bn.running_mean, bn.running_var) if update_running else (None, None)
+    check(lib().gsdd_bn_train(ptr(x), M, C_, ptr(bn.weight.detach()), ptr(bn.bias.detach()), bn.eps, momentum, ptr(rm), ptr(rv),
+                              ptr(scale), ptr(shift), ptr(ws), n, stream_ptr(stream)))
+    if update_running:
+        bn.num_batches_tracked += 1
+    return scale, shift
+
+
+def codebook_ema_stats(z, idx, K, stream=None):
+    M, E = z.shape
+    n_total = torch.empty((K,), dtype=torch.float32, device=z.device)
+    encode_sum = torch.empty((K, E), dtype=torch.float32, device=z.device)
+    dummy = torch.empty((2,), dtype=torch.float32, device=z.device)
+    check(lib().gsdd_codebook_ema(ptr(z), ptr(idx), M, E, K, 0.99, None, ptr(n_total), ptr(n_total), ptr(n_total),
+                                  ptr(n_total), ptr(encode_sum), ptr(dummy), 0, stream_ptr(stream)))
+    return n_total, encode_sum
+
+
+def codebook_ema_update(z, idx, perm, N, z_avg, emb, n_total, encode_sum, decay=0.99, stream=None):
+    M, E = z.shape
+    scalars = torch.empty((2,), dtype=torch.float32, device=z.device)
+    check(lib().gsdd_codebook_ema(ptr(z), ptr(idx), M, E, emb.shape[0], decay, ptr(perm), ptr(N), ptr(z_avg), ptr(emb),
+                                  ptr(n_total), ptr(encode_sum), ptr(scalars), 1, stream_ptr(stream)))
+    return scalars
+
+
+def mse(a, b, scale=1.0, stream=None):
+    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+    ws = torch.empty((1024,), dtype=torch.float64, device=a.device)
+    check(lib().gsdd_mse(ptr(a), ptr(b), a.numel(), scale, ptr(out), ptr(ws), 8192, stream_ptr(stream)))
+    return out[0]
+
+
 def d3pm_embed(tok, emb, pos, x, rep=1, stream=None):
     B, L = tok.shape
     check(lib().gsdd_d3pm_embed(ptr(tok), B, L, emb.shape[1], ptr(emb), emb.shape[0], ptr(pos), rep, ptr(x),

@@ -274,29 +274,40 @@ class VQVAE(nn.Module):
         return p
 
     # ------------------------------------------------------------------ HIP pipelines (channels-last rows)
-    def _res_stack(self, h, dims, rp):
+    def _res_stack(self, h, dims, rp, stack=None):
         """AttentionResidualBlock x n (videogpt_vq_vae.py:122-138); the trailing BN+ReLU is returned as a
-        prologue for the consumer.  h: rows [M][C]."""
+        prologue for the consumer.  h: rows [M][C].  `stack` (the nn.Sequential) switches to train mode: BatchNorm
+        uses batch statistics (gsdd_bn_train, running stats updated) and is applied as the consumer's prologue."""
         N, T, H, W = dims
         M, C_ = h.shape
         dev = h.device
-        for blk in rp["blocks"]:
+        train = stack is not None
+        for i, blk in enumerate(rp["blocks"]):
             a = torch.empty((M, C_ // 2), dtype=torch.float32, device=dev)
-            ops.gemm(h, blk["w3"], a, in_dims=dims, out_grid=(T, H, W), taps=blk["taps3"], ntaps=27,
-                     pro=blk["bn0"], epi_scale=blk["bn3"][0], epi_shift=blk["bn3"][1], act=ops.ACT_RELU)
             b = torch.empty((M, C_), dtype=torch.float32, device=dev)
-            ops.gemm(a, blk["w1"], b, in_dims=dims, out_grid=(T, H, W), epi_scale=blk["bn6"][0],
-                     epi_shift=blk["bn6"][1], act=ops.ACT_RELU)
             qkv = torch.empty((M, 9 * C_), dtype=torch.float32, device=dev)
-            ops.gemm(b, blk["wqkv"], qkv, in_dims=dims, out_grid=(T, H, W))
+            if train:
+                mods = stack[i].block
+                ops.gemm(h, blk["w3"], a, in_dims=dims, out_grid=(T, H, W), taps=blk["taps3"], ntaps=27,
+                         pro=ops.bn_train(h, mods[0]))
+                ops.gemm(a, blk["w1"], b, in_dims=dims, out_grid=(T, H, W), pro=ops.bn_train(a, mods[3]))
+                ops.gemm(b, blk["wqkv"], qkv, in_dims=dims, out_grid=(T, H, W), pro=ops.bn_train(b, mods[6]))
+            else:
+                ops.gemm(h, blk["w3"], a, in_dims=dims, out_grid=(T, H, W), taps=blk["taps3"], ntaps=27,
+                         pro=blk["bn0"], epi_scale=blk["bn3"][0], epi_shift=blk["bn3"][1], act=ops.ACT_RELU)
+                ops.gemm(a, blk["w1"], b, in_dims=dims, out_grid=(T, H, W), epi_scale=blk["bn6"][0],
+                         epi_shift=blk["bn6"][1], act=ops.ACT_RELU)
+                ops.gemm(b, blk["wqkv"], qkv, in_dims=dims, out_grid=(T, H, W))
             att = torch.empty((M, 3 * C_), dtype=torch.float32, device=dev)
             ops.axial_attention(qkv, dims, C_, 2, att)
             hn = torch.empty((M, C_), dtype=torch.float32, device=dev)
             ops.gemm(att, blk["wfc"], hn, in_dims=dims, out_grid=(T, H, W), epi_shift=blk["bfc"], residual=h)
             h = hn
+        if train:
+            return h, ops.bn_train(h, stack[self.n_res_layers])
         return h, rp["bn_out"]
 
-    def _encode_rows(self, x):
+    def _encode_rows(self, x, train=False):
         """x (B,3,T,H,W) on the GPU -> (z rows [M][E], latent dims)."""
         if not x.is_cuda:
             raise GsddError("VQVAE runs on the HIP path only: move the module and the input to a ROCm device")
@@ -325,12 +336,12 @@ class VQVAE(nn.Module):
         cl = p["enc_last"]
         hn = torch.empty_like(h)
         ops.gemm(h, cl["w"], hn, in_dims=dims, out_grid=dims[1:], taps=cl["taps"], ntaps=27, epi_shift=cl["bias"])
-        h, bn_out = self._res_stack(hn, dims, p["enc_res"])
+        h, bn_out = self._res_stack(hn, dims, p["enc_res"], self.encoder.res_stack if train else None)
         z = torch.empty((h.shape[0], self.embedding_dim), dtype=torch.float32, device=x.device)
         ops.gemm(h, p["pre_w"], z, in_dims=dims, out_grid=dims[1:], pro=bn_out, epi_shift=p["pre_b"])
         return z, dims
 
-    def _decode_rows(self, src, dims, gather=None):
+    def _decode_rows(self, src, dims, gather=None, train=False):
         """post_vq_conv + Decoder on rows.  src: codebook [K][E] with gather=codes, or rows [M][E]."""
         p = self.packed()
         B, T, H, W = dims
@@ -338,7 +349,7 @@ class VQVAE(nn.Module):
         dev = src.device
         h = torch.empty((M, self.n_hiddens), dtype=torch.float32, device=dev)
         ops.gemm(src, p["post_w"], h, in_dims=dims, out_grid=(T, H, W), gather=gather, epi_shift=p["post_b"])
-        h, pro = self._res_stack(h, dims, p["dec_res"])
+        h, pro = self._res_stack(h, dims, p["dec_res"], self.decoder.res_stack if train else None)
         n_up = len(p["dec_convts"])
         for i, ct in enumerate(p["dec_convts"]):
             s = ct["stride"]
@@ -377,19 +388,79 @@ class VQVAE(nn.Module):
         enc = encodings.contiguous().long()
         return self._decode_rows(self.packed()["codebook"], tuple(enc.shape), gather=enc.view(-1))
 
+    def _tile(self, x):
+        """Codebook._tile (videogpt_vq_vae.py:151-158): repeat + jitter when there are fewer latents than codes."""
+        d, ew = x.shape
+        if d < self.n_codes:
+            n_repeats = (self.n_codes + d - 1) // d
+            x = x.repeat(n_repeats, 1)
+            x = x + torch.randn_like(x) * (0.01 / math.sqrt(ew))
+        return x
+
+    def _draw_rows(self, z):
+        """`y[randperm][:n_codes]` (:165, :206-207) with the C1/C3 broadcast from rank 0 (:168-169, :210-211).
+        tests inject `self.perm_source` (a callable n -> permutation) in place of torch.randperm."""
+        import torch.distributed as dist
+        y = self._tile(z)
+        src = getattr(self, "perm_source", None)
+        perm = (src(y.shape[0]) if src is not None else torch.randperm(y.shape[0], device=z.device)).to(z.device)
+        perm = perm[: self.n_codes].long().contiguous()
+        if dist.is_available() and dist.is_initialized():
+            rows = y[perm].contiguous()
+            dist.broadcast(rows, 0)
+            return rows, torch.arange(self.n_codes, device=z.device)
+        return y.contiguous(), perm
+
+    @torch.no_grad()
+    def _forward_train(self, x):
+        """Train-mode forward value (videogpt_vq_vae.py:58-72 with Codebook.forward :174-222): BatchNorm batch statistics
+        + running-stat update, codebook data-init on the first call, EMA update with all-reduced statistics (C2) and
+        dead-code restart.  No backward exists on the HIP path yet."""
+        import torch.distributed as dist
+        cb = self.codebook
+        z, dims = self._encode_rows(x, train=True)
+        if cb._need_init:                                              # _init_embeddings (:160-172)
+            cb._need_init = False
+            rows, perm = self._draw_rows(z)
+            k_rand = rows[perm]
+            cb.embeddings.data.copy_(k_rand)
+            cb.z_avg.data.copy_(k_rand)
+            cb.N.data.fill_(1.0)
+        idx = torch.empty((z.shape[0],), dtype=torch.int64, device=z.device)
+        zq = torch.empty_like(z)
+        ops.nearest_code(z, cb.embeddings.contiguous(), idx, zq)
+        commitment = ops.mse(z, zq, 0.25)
+        n_total, encode_sum = ops.codebook_ema_stats(z, idx, self.n_codes)
+        if dist.is_available() and dist.is_initialized():               # C2 (:196-198)
+            dist.all_reduce(n_total)
+            dist.all_reduce(encode_sum)
+        rows, perm = self._draw_rows(z)
+        scal = ops.codebook_ema_update(rows, idx, perm, cb.N, cb.z_avg, cb.embeddings, n_total, encode_sum)
+        emb_st = ((zq - z) + z).contiguous()
+        x_recon = self._decode_rows(emb_st, dims, train=True)
+        recon = ops.mse(x_recon, x, 1.0 / 0.06)
+        self._packed = None                                             # BN running stats / codebook changed in place
+        return {"pred_data": x_recon, "gt_data": x,
+                "losses": {"recon_loss": recon, "commitment_loss": commitment}, "perplexity": scal[1], "encodings": idx.view(dims)}
+
     def forward(self, batch, do_inference=False):
-        if self.training:
-            raise NotImplementedError("VQ-VAE training (BatchNorm batch statistics, codebook EMA, backward) is not "
-                                      "built yet on the HIP path; call .eval() for encode/decode/forward")
         x = batch["video"].to(self.device).contiguous().float()
+        if self.training:
+            if torch.is_grad_enabled():
+                raise NotImplementedError("the VQ-VAE backward pass is not built on the HIP path yet; the train-mode "
+                                          "forward value is available under torch.no_grad()")
+            out = self._forward_train(x)
+            out.pop("encodings")
+            out.pop("perplexity")
+            return out
         with torch.no_grad():
             z, dims = self._encode_rows(x)
             idx = torch.empty((z.shape[0],), dtype=torch.int64, device=z.device)
             zq = torch.empty_like(z)
             ops.nearest_code(z, self.packed()["codebook"], idx, zq)
-            commitment = 0.25 * torch.mean((z - zq) ** 2)
+            commitment = ops.mse(z, zq, 0.25)
             emb_st = ((zq - z) + z).contiguous()
             x_recon = self._decode_rows(emb_st, dims)
-            recon = torch.mean((x_recon - x) ** 2) / 0.06
+            recon = ops.mse(x_recon, x, 1.0 / 0.06)
         return {"pred_data": x_recon, "gt_data": x,
                 "losses": {"recon_loss": recon, "commitment_loss": commitment}}

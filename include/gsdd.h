@@ -96,6 +96,28 @@ int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W, int C, in
 int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K,
                       int64_t* idx, float* zq, void* stream);
 
+/* ------------------------------------------------------------------ VQ-VAE train-mode forward pieces
+ * nn.BatchNorm3d in train mode on rows x[M][C] (videogpt_vq_vae.py:125-133, 242-247): batch mean / biased variance ->
+ * folded scale = w/sqrt(var+eps), shift = b - mean*scale (consumed by gsdd_gemm's pro_scale/pro_shift); running stats
+ * (may be NULL) updated with momentum and the unbiased variance like torch. */
+int64_t gsdd_bn_train_workspace_bytes(int64_t M, int C);
+int gsdd_bn_train(const float* x, int64_t M, int C, const float* weight, const float* bias, float eps, float momentum,
+                  float* running_mean, float* running_var, float* scale, float* shift, void* workspace,
+                  int64_t workspace_bytes, void* stream);
+
+/* Codebook EMA (Codebook.forward, videogpt_vq_vae.py:193-214) in two phases so the caller can all-reduce between them
+ * (:196-198): phase 0: n_total[K], encode_sum[K][E] from (z rows, idx); phase 1: N, z_avg EMA with `decay`, Laplace-
+ * smoothed embeddings, dead codes (N < 1) restarted from z[perm[k]] (:205-214).  scalars[0] = sum(N), scalars[1] =
+ * perplexity (:218-219). */
+int gsdd_codebook_ema(const float* z, const int64_t* idx, int64_t M, int E, int K, float decay, const int64_t* perm,
+                      float* N, float* z_avg, float* embeddings, float* n_total, float* encode_sum, float* scalars,
+                      int phase, void* stream);
+
+/* out[0] = scale * mean((a-b)^2), deterministic fp64 two-stage reduction (F.mse_loss at videogpt_vq_vae.py:64, :190);
+ * workspace >= 8 KiB. */
+int gsdd_mse(const float* a, const float* b, int64_t n, float scale, float* out, void* workspace, int64_t workspace_bytes,
+             void* stream);
+
 /* ------------------------------------------------------------------ D3PM denoiser pieces
  * x[b][l][:] = emb[tok[b][l]] + pos[l]   (DalleMaskImageEmbedding.forward, dalle_mask_image_embedding.py:59-79;
  * pos = height_emb[l/W]+width_emb[l%W] precomputed once). rep: x is written for `rep` stacked copies. */

@@ -163,3 +163,70 @@ def forward_eval(x, sd, cfg):
     return {"pred_data": rec, "gt_data": x,
             "losses": {"recon_loss": F.mse_loss(rec, x) / 0.06, "commitment_loss": commitment},
             "encodings": idx}
+
+
+# ----------------------------------------------------------------------------- train-mode forward (no grad)
+def bn_train(x, sd, p, out_sd, eps=1e-5, momentum=0.1):
+    """nn.BatchNorm3d in train mode: batch statistics, running stats updated with the unbiased variance."""
+    rm, rv = sd[p + "running_mean"].clone(), sd[p + "running_var"].clone()
+    y = F.batch_norm(x, rm, rv, sd[p + "weight"], sd[p + "bias"], True, momentum, eps)
+    out_sd[p + "running_mean"], out_sd[p + "running_var"] = rm, rv
+    out_sd[p + "num_batches_tracked"] = sd[p + "num_batches_tracked"] + 1
+    return y
+
+
+def _res_stack_train(x, sd, p, n, out_sd):
+    for i in range(n):
+        q = f"{p}{i}."
+        h = F.relu(bn_train(x, sd, q + "block.0.", out_sd))
+        h = same_pad_conv3d(h, sd[q + "block.2.conv.weight"], None, (1, 1, 1))
+        h = F.relu(bn_train(h, sd, q + "block.3.", out_sd))
+        h = same_pad_conv3d(h, sd[q + "block.5.conv.weight"], None, (1, 1, 1))
+        h = F.relu(bn_train(h, sd, q + "block.6.", out_sd))
+        x = x + axial_block(h, sd, q + "block.8.")
+    return F.relu(bn_train(x, sd, f"{p}{n}.", out_sd))
+
+
+def forward_train(x, sd, cfg, perm):
+    """Reference: VQVAE.forward with self.training (videogpt_vq_vae.py:58-72) and Codebook.forward's EMA branch
+    (:193-214) for an already-initialised codebook; `perm` replaces torch.randperm (:206).  Returns the output dict
+    and the updated buffers (same names as the state_dict)."""
+    new = {}
+    h = x
+    for i, s in enumerate(conv_strides(cfg["downsample"])):
+        h = F.relu(same_pad_conv3d(h, sd[f"encoder.convs.{i}.conv.weight"], sd[f"encoder.convs.{i}.conv.bias"], s))
+    h = same_pad_conv3d(h, sd["encoder.conv_last.conv.weight"], sd["encoder.conv_last.conv.bias"], (1, 1, 1))
+    h = _res_stack_train(h, sd, "encoder.res_stack.", cfg["n_res_layers"], new)
+    z = same_pad_conv3d(h, sd["pre_vq_conv.conv.weight"], sd["pre_vq_conv.conv.bias"], (1, 1, 1))
+    E = sd["codebook.embeddings"]
+    K = E.shape[0]
+    idx, _ = nearest_code(z, E)
+    flat = z.permute(0, 2, 3, 4, 1).reshape(-1, z.shape[1])
+    emb = F.embedding(idx, E).permute(0, 4, 1, 2, 3).contiguous()
+    commitment = 0.25 * F.mse_loss(z, emb)
+    onehot = F.one_hot(idx.view(-1), K).type_as(flat)
+    n_total = onehot.sum(dim=0)
+    encode_sum = flat.t() @ onehot
+    N = sd["codebook.N"] * 0.99 + 0.01 * n_total
+    z_avg = sd["codebook.z_avg"] * 0.99 + 0.01 * encode_sum.t()
+    n = N.sum()
+    weights = (N + 1e-7) / (n + K * 1e-7) * n
+    newE = z_avg / weights.unsqueeze(1)
+    assert flat.shape[0] >= K, "tiling branch (_tile, :151-158) is not restated"
+    k_rand = flat[torch.from_numpy(perm).long()][:K]
+    usage = (N.view(K, 1) >= 1).float()
+    newE = newE * usage + k_rand * (1 - usage)
+    new.update({"codebook.N": N, "codebook.z_avg": z_avg, "codebook.embeddings": newE})
+    emb_st = (emb - z) + z
+    h = same_pad_conv3d(emb_st, sd["post_vq_conv.conv.weight"], sd["post_vq_conv.conv.bias"], (1, 1, 1))
+    h = _res_stack_train(h, sd, "decoder.res_stack.", cfg["n_res_layers"], new)
+    strides = conv_strides(cfg["downsample"])
+    for i, s in enumerate(strides):
+        h = same_pad_convT3d(h, sd[f"decoder.convts.{i}.convt.weight"], sd[f"decoder.convts.{i}.convt.bias"], s)
+        if i < len(strides) - 1:
+            h = F.relu(h)
+    avg = onehot.mean(dim=0)
+    perplexity = torch.exp(-torch.sum(avg * torch.log(avg + 1e-10)))
+    out = {"pred_data": h, "gt_data": x, "losses": {"recon_loss": F.mse_loss(h, x) / 0.06, "commitment_loss": commitment},
+           "perplexity": perplexity, "encodings": idx}
+    return out, new

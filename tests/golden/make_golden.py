@@ -250,6 +250,57 @@ def main():
     make_d3pm("d3pm_L64", K=32, L=64, spatial=[8, 8], n_layer=2, cond_dim=32, T=100, B=2, seed=21,
               noise_seed=1234)
     torch.rand_like = real_rand_like
+    make_vqvae_train("vqvae_train_ds188", dict(embedding_dim=8, n_codes=32, n_hiddens=16, n_res_layers=1,
+                                               downsample=[1, 8, 8], sequence_length=4, resolution=32), B=2, seed=31)
+
+
+
+
+
+# --------------------------------------------------------------------------- VQ-VAE train-mode forward
+def make_vqvae_train(name, cfg, B, seed):
+    """One train-mode forward (BatchNorm batch statistics + running-stat update, codebook EMA + restart) with the
+    permutations drawn by the codebook captured, from a state saved *before* the step."""
+    from src.models.networks.videogpt_vq_vae import VQVAE
+
+    torch.manual_seed(seed)
+    m = VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"],
+              cfg["downsample"], cfg["sequence_length"], cfg["resolution"])
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm3d):
+            mod.weight.data = 1.0 + 0.2 * torch.randn(mod.weight.shape, generator=g)
+            mod.bias.data = 0.1 * torch.randn(mod.bias.shape, generator=g)
+    shape = (B, 3, cfg["sequence_length"], cfg["resolution"], cfg["resolution"])
+    perms = []
+    real_randperm = torch.randperm
+
+    def cap_randperm(n, *a, **k):
+        p = real_randperm(n, generator=g)
+        perms.append(p.numpy().copy())
+        return p
+
+    torch.randperm = cap_randperm
+    m.train()
+    with torch.no_grad():
+        m({"video": torch.randn(shape, generator=g)})            # step 0: codebook init (consumes 2 permutations)
+        perms.clear()
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        x = torch.randn(shape, generator=g)
+        out = m({"video": x})                                     # the recorded step (1 permutation: restart draw)
+    torch.randperm = real_randperm
+    res = {}
+    res.update(sd_to_np(before, "sd/"))
+    res.update(sd_to_np(m.state_dict(), "after/"))
+    res.update({"x": x.numpy(), "perm": np.stack(perms), "pred": out["pred_data"].numpy(),
+                "recon_loss": out["losses"]["recon_loss"].numpy(),
+                "commitment_loss": out["losses"]["commitment_loss"].numpy(),
+                "cfg_embedding_dim": cfg["embedding_dim"], "cfg_n_codes": cfg["n_codes"],
+                "cfg_n_hiddens": cfg["n_hiddens"], "cfg_n_res_layers": cfg["n_res_layers"],
+                "cfg_downsample": np.array(cfg["downsample"]), "cfg_sequence_length": cfg["sequence_length"],
+                "cfg_resolution": cfg["resolution"]})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    print(name, "perms:", len(perms), "codes >=1 usage:", int((m.codebook.N >= 1).sum()))
 
 
 if __name__ == "__main__":

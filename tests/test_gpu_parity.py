@@ -294,3 +294,38 @@ def test_discrete_diffusion_glue_forward(G, golden):
     assert tuple(out["pred_data"].shape) == tuple(av["x"].shape) and torch.isfinite(out["pred_data"]).all()
     assert out["losses"].ndim == 0 and torch.isfinite(out["losses"])
     torch.testing.assert_close(out["test"].cpu(), torch.from_numpy(av["decoded"]), atol=1e-4, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- VQ-VAE train-mode forward value
+def test_vqvae_train_forward_matches_reference(G):
+    import os
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "vqvae_train_ds188.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    after = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("after/")}
+    cfg = {k[4:]: (z[k].tolist() if z[k].ndim else z[k].item()) for k in z.files if k.startswith("cfg_")}
+    m = build_vqvae(G, sd, cfg)
+    m.train()
+    m.codebook._need_init = False
+    perm = torch.from_numpy(z["perm"][0])
+    m.perm_source = lambda n: perm
+    with pytest.raises(NotImplementedError):          # no backward on the HIP path: must be loud, not silent
+        m({"video": dev(z["x"])})
+    with torch.no_grad():
+        out = m({"video": dev(z["x"])})
+    torch.testing.assert_close(out["pred_data"].cpu(), torch.from_numpy(z["pred"]), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(out["losses"]["recon_loss"].item(), z["recon_loss"], rtol=1e-4)
+    np.testing.assert_allclose(out["losses"]["commitment_loss"].item(), z["commitment_loss"], rtol=1e-4)
+    got = {k: v.cpu() for k, v in m.state_dict().items()}
+    for k, v in after.items():
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(got[k], v, atol=5e-5, rtol=2e-4, msg=lambda s, k=k: f"{k}: {s}")
+        else:
+            assert torch.equal(got[k], v), k
+    # the eval path must see the updated statistics (packed-weight cache invalidated)
+    m.eval()
+    rec = m.decode(torch.zeros((1, 4, 4, 4), dtype=torch.long, device="cuda"))
+    from oracle import vqvae as ov
+    with torch.no_grad():
+        want = ov.decode(torch.zeros((1, 4, 4, 4), dtype=torch.long), after, cfg)
+    torch.testing.assert_close(rec.cpu(), want, atol=1e-4, rtol=1e-4)

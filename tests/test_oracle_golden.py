@@ -90,3 +90,22 @@ def test_train_loss_matches_reference(golden):
     np.testing.assert_allclose(loss.item(), a["train_loss"], rtol=1e-5)
     np.testing.assert_allclose(probs.numpy(), a["train_logits"], atol=1e-5)
     assert np.array_equal(pred.numpy(), a["train_pred"])
+
+
+def test_vqvae_train_forward_matches_reference():
+    from tests.conftest import GOLDEN
+    import os
+    z = np.load(os.path.join(GOLDEN, "vqvae_train_ds188.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    after = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("after/")}
+    cfg = {k[4:]: (z[k].tolist() if z[k].ndim else z[k].item()) for k in z.files if k.startswith("cfg_")}
+    with torch.no_grad():
+        out, new = vqvae.forward_train(torch.from_numpy(z["x"]), sd, cfg, z["perm"][0])
+    np.testing.assert_allclose(out["pred_data"].numpy(), z["pred"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["losses"]["recon_loss"].item(), z["recon_loss"], rtol=1e-5)
+    np.testing.assert_allclose(out["losses"]["commitment_loss"].item(), z["commitment_loss"], rtol=1e-5)
+    for k, v in new.items():
+        if v.dtype.is_floating_point:
+            np.testing.assert_allclose(v.numpy(), after[k].numpy(), atol=2e-5, rtol=1e-4, err_msg=k)
+        else:
+            assert torch.equal(v, after[k]), k
