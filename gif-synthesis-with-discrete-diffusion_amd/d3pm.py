@@ -350,6 +350,7 @@ class DiffusionTransformer(nn.Module):
         with torch.cuda.stream(st):
             condv = tr.cond_vectors(conds.contiguous())
             ws = tr.workspace(rep * B, L, dev)
+            self._last_ws = ws                  # bench.py times the dominant kernel on these in-situ operands
             tok = torch.full((B, L), K, dtype=torch.int64, device=dev)                   # all [MASK] (:613-618)
             t2 = torch.full((rep * B,), T - 1, dtype=torch.int64, device=dev)
             sid = torch.tensor([self.noise_stream], dtype=torch.int64, device=dev)
