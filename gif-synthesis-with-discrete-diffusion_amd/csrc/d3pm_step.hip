@@ -463,6 +463,170 @@ __global__ __launch_bounds__(256) void d3pm_train_finalize_kernel(TrainFinArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Gradient of the training objective w.r.t. the denoiser logits (backward of predict_start -> q_posterior -> KL / NLL /
+// aux KL, diffusion_transformer.py:391-457).  Per position, with G_c = dL/d log_model_c = -(g_kl exp(log_true_c) + g_nll w0_c):
+//   lm = clamp(e + lq1 + S), e = lae(qn + alpha, beta), qn = q - S, S = lse(q), q_k = r_k - lqt_k, r = clamp(log_softmax(x))
+// g_* are the per-sample weights of the three sums in loss = sum_b vb_b / (B L).
+struct TrainBwdArgs {
+    const float* logits; const int64_t* x0; const int64_t* xt; const int64_t* t_dev; const float* pt;
+    int B, L, K, T;
+    float mw_mask, mw_other, aux_weight; int adaptive;
+    float* dlogits;
+};
+
+template <int J>
+__global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, SchedPtrs sp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= (int64_t)d.B * d.L) return;
+    const int b = (int)(pos / d.L);
+    const int K = d.K;
+    const float NEG = -INFINITY;
+    float a[J][4];                                  // unclamped log_softmax
+    const float* row = d.logits + pos * (int64_t)K;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = 4 * lane + 256 * j;
+        if (k < K) {
+            const float4 v = *reinterpret_cast<const float4*>(row + k);
+            a[j][0] = v.x; a[j][1] = v.y; a[j][2] = v.z; a[j][3] = v.w;
+        } else {
+            a[j][0] = a[j][1] = a[j][2] = a[j][3] = NEG;
+        }
+    }
+    {   // log_softmax (fp64 sum) without the clamp
+        float mx = NEG;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, a[j][e]);
+        mx = wave_max(mx);
+        double se = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) se += (double)expf(a[j][e] - mx);
+        se = wave_sum(se);
+        const double lse = (double)mx + log(se);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[j][e] = (float)((double)a[j][e] - lse);
+    }
+    const int64_t t = d.t_dev[b];
+    const StepSched s = load_sched(sp.p, t, d.T);
+    const int64_t xt = d.xt[pos], x0 = d.x0[pos];
+    const bool masked = (xt == K);
+    const float qt_hit = lae(0.f + s.lca, s.lcb), qt_miss = lae(LOG_ZERO + s.lca, s.lcb);
+    const float q1_hit = lae(0.f + s.la, s.lb), q1_miss = lae(LOG_ZERO + s.la, s.lb);
+    // per-sample weights
+    const float m0 = (t == 0) ? 1.f : 0.f;
+    const float mw = masked ? d.mw_mask : d.mw_other;
+    const float inv = 1.f / (d.pt[b] * (float)d.B * (float)d.L);
+    const float w = d.adaptive ? ((1.f - (float)t / (float)d.T) + 1.0f) : 1.0f;
+    const float g_kl = (1.f - m0) * mw * inv;
+    const float g_nll = m0 * (1.f + w * d.aux_weight) * inv;
+    const float g_aux = (1.f - m0) * w * d.aux_weight * mw * inv;
+    // normalisers of the model / true posteriors
+    float mxm = LOG_ZERO, mxt = LOG_ZERO;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            if (k < K) {
+                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+                mxm = fmaxf(mxm, clamp70(a[j][e]) - log_qt);
+                mxt = fmaxf(mxt, (k == x0 ? 0.f : LOG_ZERO) - log_qt);
+            }
+        }
+    mxm = wave_max(mxm); mxt = wave_max(mxt);
+    float sem = 0.f, set = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            if (k < K) {
+                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+                sem += expf((clamp70(a[j][e]) - log_qt) - mxm);
+                set += expf(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
+            }
+        }
+    sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
+    set = wave_sum(set) + expf(LOG_ZERO - mxt);
+    const float Sm = mxm + logf(sem), St = mxt + logf(set);
+    const float E30 = expf(LOG_ZERO);
+    // pass A: Gqn_c and the gradient reaching S
+    float gq[J][4];
+    float sumGe = 0.f, sumGqn = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            gq[j][e] = 0.f;
+            if (k < K) {
+                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+                const float log_q1 = masked ? s.lc : (k == xt ? q1_hit : q1_miss);
+                const float qn = (clamp70(a[j][e]) - log_qt) - Sm;
+                const float ee = lae(qn + s.pca, s.pcb);
+                const float pre = ee + log_q1 + Sm;
+                const float lx0 = (k == x0 ? 0.f : LOG_ZERO);
+                const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
+                const float G = -(g_kl * expf(ltr) + g_nll * (k == x0 ? 1.f : E30));
+                const float Ge = (pre >= -70.f && pre <= 0.f) ? G : 0.f;
+                const float Gqn = Ge * expf((qn + s.pca) - ee);
+                gq[j][e] = Gqn;
+                sumGe += Ge; sumGqn += Gqn;
+            }
+        }
+    sumGe = wave_sum(sumGe); sumGqn = wave_sum(sumGqn);
+    {   // the [MASK] class: q_K is a constant, it only feeds S
+        const float log_q1K = masked ? 0.f : LOG_ZERO;
+        const float qnK = LOG_ZERO - Sm;
+        const float eK = lae(qnK + s.p1mcc, s.pcc);
+        const float preK = eK + log_q1K + Sm;
+        const float ltK = clamp70(lae((LOG_ZERO - St) + s.p1mcc, s.pcc) + log_q1K + St);
+        const float GK = -(g_kl * expf(ltK) + g_nll * (x0 == K ? 1.f : E30));
+        const float GeK = (preK >= -70.f && preK <= 0.f) ? GK : 0.f;
+        sumGe += GeK;
+        sumGqn += GeK * expf((qnK + s.p1mcc) - eK);
+    }
+    const float GS = sumGe - sumGqn;
+    // pass B: through q -> r -> clamp -> log_softmax
+    float sumGa = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * j + e;
+            if (k < K) {
+                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
+                const float r = clamp70(a[j][e]);
+                const float pi = expf((r - log_qt) - Sm);
+                float Gr = gq[j][e] + GS * pi;
+                Gr -= g_aux * (k == x0 ? 1.f : E30);
+                const float Ga = (a[j][e] >= -70.f && a[j][e] <= 0.f) ? Gr : 0.f;
+                gq[j][e] = Ga;
+                sumGa += Ga;
+            }
+        }
+    sumGa = wave_sum(sumGa);
+    float* drow = d.dlogits + pos * (int64_t)K;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int k = 4 * lane + 256 * j;
+        if (k < K) {
+            float4 o;
+            o.x = gq[j][0] - expf(a[j][0]) * sumGa; o.y = gq[j][1] - expf(a[j][1]) * sumGa;
+            o.z = gq[j][2] - expf(a[j][2]) * sumGa; o.w = gq[j][3] - expf(a[j][3]) * sumGa;
+            *reinterpret_cast<float4*>(drow + k) = o;
+        }
+    }
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
@@ -557,6 +721,34 @@ extern "C" int gsdd_d3pm_train_loss(const gsdd_train_desc* d, void* stream) {
     f.aux_weight = d->aux_weight; f.adaptive = d->adaptive_aux; f.Lt_history = d->Lt_history; f.Lt_count = d->Lt_count;
     f.loss = d->loss; f.per_sample = d->per_sample;
     hipLaunchKernelGGL(d3pm_train_finalize_kernel, dim3(1), dim3(256), 0, st, f);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_d3pm_train_loss_bwd(const gsdd_train_desc* d, float* dlogits, void* stream) {
+    GSDD_CHECK_ARG(d != nullptr && dlogits != nullptr, "null pointer");
+    GSDD_CHECK_ARG(d->logits && d->x0 && d->xt && d->t_dev && d->pt, "null pointer");
+    GSDD_CHECK_ARG(d->B > 0 && d->L > 0 && d->T > 0 && d->K >= 4 && d->K % 4 == 0 && d->K <= 8192, "bad sizes");
+    SchedPtrs sp;
+    for (int i = 0; i < 8; ++i) {
+        GSDD_CHECK_ARG(d->sched[i] != nullptr, "null schedule buffer");
+        sp.p[i] = d->sched[i];
+    }
+    TrainBwdArgs a;
+    a.logits = d->logits; a.x0 = d->x0; a.xt = d->xt; a.t_dev = d->t_dev; a.pt = d->pt;
+    a.B = d->B; a.L = d->L; a.K = d->K; a.T = d->T;
+    a.mw_mask = d->mask_weight[0]; a.mw_other = d->mask_weight[1]; a.aux_weight = d->aux_weight; a.adaptive = d->adaptive_aux;
+    a.dlogits = dlogits;
+    const int64_t npos = (int64_t)d->B * d->L;
+    const dim3 grid((unsigned)((npos + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int J = (d->K + 255) / 256;
+    if (J <= 1) hipLaunchKernelGGL(d3pm_train_bwd_kernel<1>, grid, block, 0, st, a, sp);
+    else if (J <= 2) hipLaunchKernelGGL(d3pm_train_bwd_kernel<2>, grid, block, 0, st, a, sp);
+    else if (J <= 4) hipLaunchKernelGGL(d3pm_train_bwd_kernel<4>, grid, block, 0, st, a, sp);
+    else if (J <= 8) hipLaunchKernelGGL(d3pm_train_bwd_kernel<8>, grid, block, 0, st, a, sp);
+    else if (J <= 16) hipLaunchKernelGGL(d3pm_train_bwd_kernel<16>, grid, block, 0, st, a, sp);
+    else hipLaunchKernelGGL(d3pm_train_bwd_kernel<32>, grid, block, 0, st, a, sp);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -291,3 +291,81 @@ class Event:
             lib().gsdd_event_destroy(self.h)
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------- training-step building blocks
+def d3pm_train_loss_bwd(logits, x0, xt, t_dev, pt, sched, *, K, T, mask_weight, aux_weight, adaptive_aux, stream=None):
+    B, L = x0.shape
+    d = TrainDesc()
+    d.logits, d.x0, d.xt, d.t_dev, d.pt = ptr(logits), ptr(x0), ptr(xt), ptr(t_dev), ptr(pt)
+    d.B, d.L, d.K, d.T = B, L, K, T
+    for i in range(8):
+        d.sched[i] = ptr(sched[i])
+    d.mask_weight[0], d.mask_weight[1] = float(mask_weight[0]), float(mask_weight[1])
+    d.aux_weight, d.adaptive_aux = float(aux_weight), int(bool(adaptive_aux))
+    dlogits = torch.empty_like(logits)
+    check(lib().gsdd_d3pm_train_loss_bwd(C.byref(d), ptr(dlogits), stream_ptr(stream)))
+    return dlogits
+
+
+def gelu2(a, du=None, stream=None):
+    out = torch.empty_like(a)
+    check(lib().gsdd_gelu2(ptr(a), ptr(du), ptr(out), a.numel(), 0 if du is None else 1, stream_ptr(stream)))
+    return out
+
+
+def ln_bwd(dh, x, stats, gamma, *, sel=None, gstride=0, rows_per_batch=1, dx_in=None, dgamma=None, dbeta=None,
+           gacc_stride=0, acc_by_batch=False, stream=None):
+    dx = torch.empty_like(x)
+    check(lib().gsdd_ln_bwd(ptr(dh), ptr(x), ptr(stats), ptr(gamma), ptr(sel), gstride, rows_per_batch, x.shape[0], x.shape[1],
+                            ptr(dx_in), ptr(dx), ptr(dgamma), ptr(dbeta), gacc_stride, int(acc_by_batch), stream_ptr(stream)))
+    return dx
+
+
+def wgrad(dY, X, dW, db=None, stream=None):
+    """dW[N][K] += dY^T X ; db[N] += colsum(dY)"""
+    check(lib().gsdd_wgrad(ptr(dY), dY.shape[1], ptr(X), X.shape[1], dY.shape[0], dY.shape[1], X.shape[1], ptr(dW), ptr(db),
+                           stream_ptr(stream)))
+
+
+def colsum(Y, out, stream=None):
+    check(lib().gsdd_colsum(ptr(Y), Y.shape[1], Y.shape[0], Y.shape[1], ptr(out), stream_ptr(stream)))
+
+
+def batch_rowsum(Y, B, L, stream=None):
+    out = torch.empty((B, Y.shape[1]), dtype=torch.float32, device=Y.device)
+    check(lib().gsdd_batch_rowsum(ptr(Y), B, L, Y.shape[1], ptr(out), stream_ptr(stream)))
+    return out
+
+
+def d3pm_attention_train(q, k, v, B, L, H, out, lse, stream=None):
+    check(lib().gsdd_d3pm_attention_train(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(lse), stream_ptr(stream)))
+
+
+def d3pm_attention_bwd(q, k, v, o, dO, lse, B, L, H, stream=None):
+    dqkv = torch.empty((B * L, 3 * H * 4), dtype=torch.float32, device=q.device)
+    scratch = torch.empty((H * B * L,), dtype=torch.float32, device=q.device)
+    check(lib().gsdd_d3pm_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), B, L, H, ptr(dqkv), ptr(scratch),
+                                        stream_ptr(stream)))
+    return dqkv
+
+
+def d3pm_embed_bwd(dx, tok, demb, dpos, stream=None):
+    B, L = tok.shape
+    check(lib().gsdd_d3pm_embed_bwd(ptr(dx), ptr(tok), B, L, dx.shape[1], demb.shape[0], ptr(demb), ptr(dpos), stream_ptr(stream)))
+
+
+def small_linear_bwd(dy, x, w, dw, db=None, want_dx=True, stream=None):
+    R, Cin = x.shape
+    dx = torch.empty_like(x) if want_dx else None
+    check(lib().gsdd_small_linear_bwd(ptr(dy), ptr(x), ptr(w), R, Cin, w.shape[0], ptr(dx), ptr(dw), ptr(db), stream_ptr(stream)))
+    return dx
+
+
+def adaln_bwd(dtab, t, emb, w, demb, dw, db, stream=None):
+    check(lib().gsdd_adaln_bwd(ptr(dtab), ptr(t), dtab.shape[0], emb.shape[1], ptr(emb), ptr(w), ptr(demb), ptr(dw), ptr(db),
+                               stream_ptr(stream)))
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, stream=None):
+    check(lib().gsdd_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream_ptr(stream)))

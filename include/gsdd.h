@@ -228,6 +228,43 @@ typedef struct {
 } gsdd_train_desc;
 int gsdd_d3pm_train_loss(const gsdd_train_desc* d, void* stream);
 
+/* dlogits = d loss / d logits of the objective above (backward of predict_start -> q_posterior -> KL / NLL / aux KL). */
+int gsdd_d3pm_train_loss_bwd(const gsdd_train_desc* d, float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------ D3PM training step: backward building blocks
+ * (autograd of transformer_utils.py:24-62, 138-159, 258-282, 353-356 and dalle_mask_image_embedding.py:59-79) */
+/* out = gelu2(a) (backward=0) or out = du * gelu2'(a) (backward=1), n % 4 == 0 */
+int gsdd_gelu2(const float* a, const float* du, float* out, int64_t n, int backward, void* stream);
+/* LayerNorm backward over rows of 64: dx_out = dx_in + LN'(dh); dgamma/dbeta accumulated (+=) per batch element
+ * (acc_by_batch, AdaLN table rows) or globally (affine LN).  gamma = gamma_base + sel[b]*gstride. */
+int gsdd_ln_bwd(const float* dh, const float* x, const float* stats, const float* gamma, const int64_t* sel, int gstride,
+                int rows_per_batch, int64_t M, int C, const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
+                int gacc_stride, int acc_by_batch, void* stream);
+/* dW[N][K] += dY^T X (contraction over the M rows), db[N] += column sums of dY (optional) */
+int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int64_t M, int N, int K, float* dW, float* db, void* stream);
+/* out[n] += sum_m Y[m][n] */
+int gsdd_colsum(const float* Y, int ld, int64_t M, int N, float* out, void* stream);
+/* out[b][c] = sum_l Y[b*L+l][c] */
+int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out, void* stream);
+/* head-dim-4 self-attention for training: forward that also returns the log2-domain log-sum-exp per (head,row), and the
+ * backward (dq|dk|dv rows [M][3*H*4]); scratch: float[H*M]. */
+int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
+                              void* stream);
+int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
+                            int B, int L, int H, float* dqkv, float* scratch, void* stream);
+/* demb[tok] += dx, dpos[l] += dx */
+int gsdd_d3pm_embed_bwd(const float* dx, const int64_t* tok, int B, int L, int D, int n_embed, float* demb, float* dpos,
+                        void* stream);
+/* y = W x + b over R rows: dx (optional) = dy W ; dW += dy^T x ; db (optional) += sum dy */
+int gsdd_small_linear_bwd(const float* dy, const float* x, const float* w, int R, int Cin, int Cout, float* dx, float* dw,
+                          float* db, void* stream);
+/* backward of gsdd_adaln_table restricted to the rows t[b]: dtab [B][2D] -> demb (+=, rows t[b]), dW (+=), db (+=) */
+int gsdd_adaln_bwd(const float* dtab, const int64_t* t, int B, int D, const float* emb, const float* w, float* demb, float* dw,
+                   float* db, void* stream);
+/* torch.optim.Adam update (no weight decay), step >= 1 */
+int gsdd_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+              void* stream);
+
 /* t[b] += dt ; stream[0] += ds   (device-side loop counters for the captured step graph) */
 int gsdd_advance(int64_t* t_dev, int B, int64_t dt, int64_t* stream_dev, int64_t ds, void* stream);
 
