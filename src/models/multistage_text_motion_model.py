@@ -34,9 +34,19 @@ class MultistageTextMotionModel(BaseModel):
         return {"pred_data": clips, "gt_data": batch.get("video")}
 
     def allsplit_step(self, split, batch, batch_idx):
+        """train: one optimiser step of the D3PM generator on the HIP path (zero_grad -> backward -> Adam in the reference,
+        multistage_text_motion_model.py:186-197; here gsdd_amd.d3pm_train.D3PMTrainer.step, which also averages
+        gradients over the data-parallel group).  The autoencoder stays frozen in eval mode (auto_lr 1e-6 in the
+        reference is effectively a no-op and its backward is not built)."""
         if split == "train":
-            out = self.generator_step(batch)
-            loss = torch.mean(out["losses"])
+            from gsdd_amd.d3pm_train import D3PMTrainer
+            if getattr(self, "_trainer", None) is None:
+                self._trainer = D3PMTrainer(self.generator.diffusion_model, lr=self.lr_args.get("gen_lr", 1e-4))
+            with torch.no_grad():
+                x = batch["video"].to(self.autoencoder.device)
+                tokens = self.autoencoder.encode(x).view(x.shape[0], -1)
+                text_emb = torch.zeros_like(self.generator.textencoder(batch["text"]).unsqueeze(1).to(tokens.device))
+            loss = self._trainer.step(tokens, text_emb)[0]
             self.log_dict({f"total/{split}": float(loss)})
             return loss
         return self.sample_generator_step(batch)

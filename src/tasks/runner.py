@@ -37,10 +37,12 @@ def train(cfg):
     opts = opts if isinstance(opts, (list, tuple)) else [opts]
     for epoch in range(cfg.trainer.get("max_epochs", 1)):
         for i, batch in enumerate(datamodule.train_dataloader()):
-            loss = model.training_step(batch, i)        # raises NotImplementedError until the HIP backward exists
-            for o in opts:
-                o.zero_grad()
-            loss.backward()
-            for o in opts:
-                o.step()
+            loss = model.training_step(batch, i)        # stage 2: a full optimiser step on the HIP path
+            if loss.requires_grad:                      # (stage 1 / VQ-VAE: backward not built on the HIP path yet)
+                for o in opts:
+                    o.zero_grad()
+                loss.backward()
+                for o in opts:
+                    o.step()
+            print(f"epoch {epoch} step {i} loss {float(loss):.5f}")
     return {}

@@ -94,3 +94,59 @@ def test_adam_step_matches_torch(G, golden):
         assert torch.allclose(d_got[big], d_ref[big], atol=2e-6, rtol=2e-2), k
     # the sampler must see the updated weights (packed cache invalidated)
     assert dm.transformer._packed is None
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import gsdd_amd
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    from gsdd_amd.parallel import shard_batch
+    from tests.conftest import load_golden
+    dist.init_process_group("gloo")                  # rehearsal backend: both ranks share the box's single GPU
+    torch.cuda.set_device(0)
+    sd, a, cfg = load_golden("d3pm_L64")
+    dm = build(gsdd_amd, sd, cfg)
+    start, count = shard_batch(cfg["B"], world, rank)
+    dm.set_noise(cfg["noise_seed"], stream=int(a["train_stream"]), row_offset=start)
+    t = torch.tensor([5, 77])[start:start + count].cuda()
+    tr = D3PMTrainer(dm)
+    tr.step(torch.from_numpy(a["train_x0"])[start:start + count].cuda(), torch.from_numpy(a["step_cond"])[start:start + count].cuda(),
+            t=t, pt=(torch.ones(count) / cfg["T"]).cuda())
+    if rank == 0:
+        q.put({k: v.detach().cpu().numpy() for k, v in dm.transformer.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_global_batch(G, golden):
+    """2 ranks x batch 1 with gradient all-reduce == 1 process x batch 2 (the loss is a mean over B*L)."""
+    import os
+    import torch.multiprocessing as mp
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    sd, a, cfg = golden("d3pm_L64")
+    dm = build(G, sd, cfg)
+    dm.set_noise(cfg["noise_seed"], stream=int(a["train_stream"]))
+    tr = D3PMTrainer(dm)
+    tr.step(torch.from_numpy(a["train_x0"]).cuda(), torch.from_numpy(a["step_cond"]).cuda(), t=torch.tensor([5, 77]).cuda(),
+            pt=(torch.ones(2) / cfg["T"]).cuda())
+    single = {k: v.detach().cpu() for k, v in dm.transformer.named_parameters()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _, want_g = oracle_grads(sd, a, cfg, torch.tensor([5, 77]))
+    gmax = max(v.abs().max().item() for v in want_g.values())
+    for k, v in single.items():
+        if want_g[k].abs().max().item() < 1e-4 * gmax:
+            continue
+        d1, d2 = v - sd["transformer." + k], torch.from_numpy(got[k]) - sd["transformer." + k]
+        big = want_g[k].abs() > 1e-2 * want_g[k].abs().max()
+        assert torch.allclose(d1[big], d2[big], atol=5e-6, rtol=5e-2), k
