@@ -13,7 +13,8 @@ _lib = None
 EXPORTS = [
     "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
     "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
-    "gsdd_codebook_ema", "gsdd_mse", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
+    "gsdd_codebook_ema", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
+    "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
     "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_gelu2", "gsdd_ln_bwd", "gsdd_wgrad",
     "gsdd_batch_rowsum", "gsdd_colsum", "gsdd_d3pm_attention_train", "gsdd_d3pm_attention_bwd", "gsdd_d3pm_embed_bwd", "gsdd_small_linear_bwd",
     "gsdd_adaln_bwd", "gsdd_adam", "gsdd_advance",
@@ -87,7 +88,14 @@ def lib():
         L.gsdd_nearest_code.argtypes = [_p, _i64, _i, _p, _i, _p, _p, _p]
         L.gsdd_bn_train_workspace_bytes.argtypes = [_i64, _i]
         L.gsdd_bn_train_workspace_bytes.restype = _i64
-        L.gsdd_bn_train.argtypes = [_p, _i64, _i, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _p, _i64, _p]
+        L.gsdd_bn_train.argtypes = [_p, _i64, _i, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _p, _p, _i64, _p]
+        L.gsdd_conv_wgrad.argtypes = [C.POINTER(GemmDesc), _p, _i, _p, _p]
+        L.gsdd_bn_relu_bwd_workspace_bytes.argtypes = [_i64, _i]
+        L.gsdd_bn_relu_bwd_workspace_bytes.restype = _i64
+        L.gsdd_bn_relu_bwd.argtypes = [_p, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]
+        L.gsdd_relu_mask.argtypes = [_p, _p, _p, _i64, _p]
+        L.gsdd_lincomb.argtypes = [_p, _p, _p, C.c_float, _p, _i64, _p]
+        L.gsdd_axial_attention_bwd.argtypes = [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]
         L.gsdd_codebook_ema.argtypes = [_p, _p, _i64, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p, _i, _p]
         L.gsdd_mse.argtypes = [_p, _p, _i64, C.c_float, _p, _p, _i64, _p]
         L.gsdd_d3pm_embed.argtypes = [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p]

@@ -1,0 +1,292 @@
+// Backward kernels of the VQ-VAE training step (correctness-first): implicit-GEMM weight gradient with tap tables and the
+// BN+ReLU prologue, BatchNorm(train)+ReLU backward, ReLU masks, axial-attention backward, small elementwise helpers.
+// Data gradients of (transposed) convolutions reuse gsdd_gemm with transposed weights and mirrored tap tables.
+// Reference semantics: autograd of videogpt_vq_vae.py:102-138, 228-332 and model_utils.py:211-289, 318-337, 586-600.
+#include "common.hpp"
+
+namespace gsdd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ conv weight gradient
+//   dW[tap][n][c] += sum_m dY[orow(m)][n] * pro(X[src(m,tap)][c])
+// grid: (row slabs, n-tiles * c-tiles, taps); 128 rows per slab iteration, 64x64 output tile, 4 waves (32x32 quadrants)
+constexpr int CW_ROWS = 128;
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const gsdd_gemm_desc d, const float* dY, int dy_pitch, float* dW,
+                                                         const int64_t M, int slabs, int ctiles) {
+    __shared__ float sy[CW_ROWS][64], sx[CW_ROWS][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = (blockIdx.y / ctiles) * 64, c0 = (blockIdx.y % ctiles) * 64;
+    const int tap = blockIdx.z;
+    const int wn = wave >> 1, wk = wave & 1;
+    int dt = 0, dh = 0, dw = 0;
+    if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
+    const bool linear_rows = (d.oD == d.Do && d.oH == d.Ho && d.oW == d.Wo && d.osd == 1 && d.osh == 1 && d.osw == 1 &&
+                              d.ood == 0 && d.ooh == 0 && d.oow == 0);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int sl = 0; sl < slabs; ++sl) {
+        const int64_t r0 = ((int64_t)blockIdx.x * slabs + sl) * CW_ROWS;
+        if (r0 >= M) break;
+        __syncthreads();
+        for (int i = tid; i < CW_ROWS * 16; i += 256) {
+            const int r = i >> 4, c = (i & 15) * 4;
+            float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
+            const int64_t m = r0 + r;
+            if (m < M) {
+                uint32_t q = (uint32_t)m;
+                const uint32_t wo = q % (uint32_t)d.Wo; q /= (uint32_t)d.Wo;
+                const uint32_t ho = q % (uint32_t)d.Ho; q /= (uint32_t)d.Ho;
+                const uint32_t to = q % (uint32_t)d.Do; q /= (uint32_t)d.Do;
+                const int64_t nb = q;
+                if (n0 + c < d.Cout) {
+                    int64_t orow = m;
+                    if (!linear_rows)
+                        orow = ((nb * d.oD + ((int64_t)to * d.osd + d.ood)) * d.oH + ((int)ho * d.osh + d.ooh)) * (int64_t)d.oW +
+                               ((int)wo * d.osw + d.oow);
+                    vy = *reinterpret_cast<const float4*>(dY + orow * dy_pitch + n0 + c);
+                }
+                const int ti = (int)to * d.sd + dt, hi = (int)ho * d.sh + dh, wi = (int)wo * d.sw + dw;
+                if (c0 + c < d.Cin && (unsigned)ti < (unsigned)d.Di && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
+                    const int64_t row = ((nb * d.Di + ti) * d.Hi + hi) * (int64_t)d.Wi + wi;
+                    vx = *reinterpret_cast<const float4*>(d.in + row * d.in_pitch + c0 + c);
+                    if (d.pro_scale != nullptr) {
+                        const float4 ps = *reinterpret_cast<const float4*>(d.pro_scale + c0 + c);
+                        const float4 pb = *reinterpret_cast<const float4*>(d.pro_shift + c0 + c);
+                        vx.x = fmaxf(fmaf(vx.x, ps.x, pb.x), 0.f); vx.y = fmaxf(fmaf(vx.y, ps.y, pb.y), 0.f);
+                        vx.z = fmaxf(fmaf(vx.z, ps.z, pb.z), 0.f); vx.w = fmaxf(fmaf(vx.w, ps.w, pb.w), 0.f);
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(&sy[r][c]) = vy;
+            *reinterpret_cast<float4*>(&sx[r][c]) = vx;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int s = 0; s < CW_ROWS / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sy[2 * s + lh][wn * 32 + li], sx[2 * s + lh][wk * 32 + li], acc, 0, 0, 0);
+    }
+    float* out = dW + (int64_t)tap * d.Cout * d.Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int c = c0 + wk * 32 + li;
+        if (n < d.Cout && c < d.Cin) atomicAdd(out + (int64_t)n * d.Cin + c, acc[r]);
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm(train) + ReLU backward on rows x[M][C]
+//   a = relu(y), y = gamma*xhat + beta, xhat = (x - mean)*rstd ; given da:
+//   dy = da*[y>0] ; dbeta = sum dy ; dgamma = sum dy*xhat ; dx = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat))
+constexpr int BB_ROWS = 512;
+__global__ __launch_bounds__(256) void bn_relu_bwd_partial_kernel(const float* da, const float* x, const float* mean_rstd,
+                                                                  const float* gamma, const float* beta, int64_t M, int C,
+                                                                  double* part) {
+    const int64_t r0 = (int64_t)blockIdx.x * BB_ROWS;
+    const int64_t r1 = r0 + BB_ROWS < M ? r0 + BB_ROWS : M;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1], g = gamma[c], bt = beta[c];
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float xh = (x[r * C + c] - mu) * rs;
+            const float y = g * xh + bt;
+            const float dy = y > 0.f ? da[r * C + c] : 0.f;
+            s1 += (double)dy;
+            s2 += (double)(dy * xh);
+        }
+        part[((int64_t)blockIdx.x * C + c) * 2 + 0] = s1;
+        part[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
+    }
+}
+__global__ void bn_relu_bwd_reduce_kernel(const double* part, int nblk, int C, float* dgamma, float* dbeta, float* sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
+    dbeta[c] += (float)s1;
+    dgamma[c] += (float)s2;
+    sums[2 * c] = (float)s1;
+    sums[2 * c + 1] = (float)s2;
+}
+__global__ void bn_relu_bwd_apply_kernel(const float* da, const float* x, const float* mean_rstd, const float* gamma,
+                                         const float* beta, const float* sums, int64_t M, int C, const float* dx_in, float* dx) {
+    const int q4 = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * q4) return;
+    const int64_t r = i / q4;
+    const int c = (int)(i % q4) * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+    const float4 dv = *reinterpret_cast<const float4*>(da + r * C + c);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dx_in != nullptr) o = *reinterpret_cast<const float4*>(dx_in + r * C + c);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float res[4];
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float mu = mean_rstd[2 * (c + e)], rs = mean_rstd[2 * (c + e) + 1], g = gamma[c + e], bt = beta[c + e];
+        const float xh = (xs[e] - mu) * rs;
+        const float y = g * xh + bt;
+        const float dy = y > 0.f ? ds[e] : 0.f;
+        res[e] = g * rs * (dy - sums[2 * (c + e)] * invM - xh * sums[2 * (c + e) + 1] * invM);
+    }
+    o.x += res[0]; o.y += res[1]; o.z += res[2]; o.w += res[3];
+    *reinterpret_cast<float4*>(dx + r * C + c) = o;
+}
+
+// dpre = dout * [out > 0]   (ReLU backward through a saved post-activation)
+__global__ void relu_mask_kernel(const float* dout, const float* out, float* dpre, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 g = *reinterpret_cast<const float4*>(dout + i);
+    const float4 o = *reinterpret_cast<const float4*>(out + i);
+    *reinterpret_cast<float4*>(dpre + i) = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f,
+                                                       o.w > 0.f ? g.w : 0.f);
+}
+
+// out = (a ? a : 0) + alpha * (b - c)
+__global__ void lincomb_kernel(const float* a, const float* b, const float* c, float alpha, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (a != nullptr ? a[i] : 0.f) + alpha * (b[i] - c[i]);
+}
+
+// ------------------------------------------------------------------ axial attention backward: one wave per (line, head, axis)
+__global__ __launch_bounds__(64) void axial_attention_bwd_kernel(const float* qkv, const float* datt, int N, int T, int H, int W,
+                                                                 int C, int n_head, int axis, float* dqkv) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int head = blockIdx.y;
+    const int d = C / n_head;
+    const int S = axis == 0 ? W : (axis == 1 ? H : T);
+    const int64_t line = blockIdx.x;
+    int64_t stride, basepos;
+    if (axis == 0) { stride = 1; basepos = line * W; }
+    else if (axis == 1) { stride = W; const int64_t w = line % W; const int64_t nt = line / W; basepos = nt * H * W + w; }
+    else { stride = (int64_t)H * W; const int64_t hw = line % ((int64_t)H * W); const int64_t n = line / ((int64_t)H * W);
+           basepos = n * T * H * W + hw; }
+    const int P = d + 1;
+    float* sq = smf; float* sk = sq + S * P; float* sv = sk + S * P; float* sg = sv + S * P;      // [S][d+1] each
+    float* sp = sg + S * P;                                                                        // [S][S] probabilities
+    float* sd = sp + S * S;                                                                        // [S][S] dS
+    const int lane = threadIdx.x;
+    const int64_t rowpitch = 9 * (int64_t)C;
+    const int64_t colbase = (int64_t)axis * 3 * C + head * d;
+    for (int i = lane; i < S * d; i += 64) {
+        const int s = i / d, e = i % d;
+        const float* row = qkv + (basepos + s * stride) * rowpitch + colbase + e;
+        sq[s * P + e] = row[0]; sk[s * P + e] = row[C]; sv[s * P + e] = row[2 * C];
+        sg[s * P + e] = datt[(basepos + s * stride) * (3 * (int64_t)C) + (int64_t)axis * C + head * d + e];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)d);
+    for (int i = lane; i < S * S; i += 64) {
+        const int a = i / S, b = i % S;
+        float s = 0.f, dp = 0.f;
+        for (int e = 0; e < d; ++e) { s = fmaf(sq[a * P + e], sk[b * P + e], s); dp = fmaf(sg[a * P + e], sv[b * P + e], dp); }
+        sp[i] = s * scale;
+        sd[i] = dp;
+    }
+    __syncthreads();
+    for (int a = lane; a < S; a += 64) {
+        float mx = -INFINITY;
+        for (int j = 0; j < S; ++j) mx = fmaxf(mx, sp[a * S + j]);
+        float l = 0.f;
+        for (int j = 0; j < S; ++j) { const float p = expf(sp[a * S + j] - mx); sp[a * S + j] = p; l += p; }
+        const float inv = 1.f / l;
+        float rs = 0.f;
+        for (int j = 0; j < S; ++j) { sp[a * S + j] *= inv; rs += sp[a * S + j] * sd[a * S + j]; }
+        for (int j = 0; j < S; ++j) sd[a * S + j] = sp[a * S + j] * (sd[a * S + j] - rs) * scale;
+    }
+    __syncthreads();
+    for (int i = lane; i < S * d; i += 64) {
+        const int a = i / d, e = i % d;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < S; ++j) {
+            dq = fmaf(sd[a * S + j], sk[j * P + e], dq);
+            dk = fmaf(sd[j * S + a], sq[j * P + e], dk);
+            dv = fmaf(sp[j * S + a], sg[j * P + e], dv);
+        }
+        float* row = dqkv + (basepos + a * stride) * rowpitch + colbase + e;
+        row[0] = dq; row[C] = dk; row[2 * C] = dv;
+    }
+}
+
+}  // namespace gsdd
+
+using namespace gsdd;
+
+extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_pitch, float* dW, void* stream) {
+    GSDD_CHECK_ARG(d != nullptr && dY != nullptr && dW != nullptr && d->in != nullptr, "null pointer");
+    GSDD_CHECK_ARG(d->N > 0 && d->Do > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0 && d->Cin > 0, "bad sizes");
+    GSDD_CHECK_ARG(d->Cin % 4 == 0 && d->in_pitch % 4 == 0 && d->Cout % 4 == 0 && dy_pitch % 4 == 0, "channel counts / pitches must be multiples of 4");
+    GSDD_CHECK_ARG(d->ntaps >= 1 && (d->ntaps == 1 || d->taps != nullptr) && d->gather == nullptr && d->ln_stats == nullptr,
+                   "unsupported descriptor");
+    const int64_t M = (int64_t)d->N * d->Do * d->Ho * d->Wo;
+    GSDD_CHECK_ARG(M < (1ll << 31), "more than 2^31 rows");
+    const int slabs = 8;
+    const int ntiles = (d->Cout + 63) / 64, ctiles = (d->Cin + 63) / 64;
+    const dim3 grid((unsigned)((M + (int64_t)CW_ROWS * slabs - 1) / ((int64_t)CW_ROWS * slabs)), ntiles * ctiles, d->ntaps);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int64_t gsdd_bn_relu_bwd_workspace_bytes(int64_t M, int C) {
+    return (((M + BB_ROWS - 1) / BB_ROWS) * (int64_t)C * 2) * (int64_t)sizeof(double) + (int64_t)C * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int gsdd_bn_relu_bwd(const float* da, const float* x, int64_t M, int C, const float* mean_rstd, const float* gamma,
+                                const float* beta, const float* dx_in, float* dx, float* dgamma, float* dbeta, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    GSDD_CHECK_ARG(da && x && mean_rstd && gamma && beta && dx && dgamma && dbeta && workspace, "null pointer");
+    GSDD_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bad sizes");
+    GSDD_CHECK_ARG(workspace_bytes >= gsdd_bn_relu_bwd_workspace_bytes(M, C), "workspace too small");
+    const int nblk = (int)((M + BB_ROWS - 1) / BB_ROWS);
+    double* part = (double*)workspace;
+    float* sums = (float*)(part + (int64_t)nblk * C * 2);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(nblk), dim3(256), 0, st, da, x, mean_rstd, gamma, beta, M, C, part);
+    GSDD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, C, dgamma, dbeta, sums);
+    GSDD_CHECK_LAUNCH();
+    const int64_t n = M * (C / 4);
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, da, x, mean_rstd, gamma, beta,
+                       sums, M, C, dx_in, dx);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_relu_mask(const float* dout, const float* out, float* dpre, int64_t n, void* stream) {
+    GSDD_CHECK_ARG(dout && out && dpre && n > 0 && n % 4 == 0, "bad args");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, out, dpre, n);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_lincomb(const float* a, const float* b, const float* c, float alpha, float* out, int64_t n, void* stream) {
+    GSDD_CHECK_ARG(b && c && out && n > 0, "bad args");
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, alpha, out, n);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_axial_attention_bwd(const float* qkv, const float* datt, int N, int T, int H, int W, int C, int n_head,
+                                        float* dqkv, void* stream) {
+    GSDD_CHECK_ARG(qkv && datt && dqkv, "null pointer");
+    GSDD_CHECK_ARG(N > 0 && T > 0 && H > 0 && W > 0 && C > 0 && n_head > 0 && C % n_head == 0, "bad sizes");
+    GSDD_CHECK_ARG(T <= 64 && H <= 64 && W <= 64, "axis length > 64 unsupported");
+    const int d = C / n_head;
+    const int axes_len[3] = {W, H, T};
+    const int64_t pos = (int64_t)N * T * H * W;
+    for (int axis = 0; axis < 3; ++axis) {
+        const int S = axes_len[axis];
+        const size_t lds = (size_t)(4 * S * (d + 1) + 2 * S * S) * sizeof(float);
+        GSDD_CHECK_ARG(lds <= 64 * 1024, "line does not fit LDS");
+        hipLaunchKernelGGL(axial_attention_bwd_kernel, dim3((unsigned)(pos / S), n_head, 1), dim3(64), lds, (hipStream_t)stream, qkv,
+                           datt, N, T, H, W, C, n_head, axis, dqkv);
+        GSDD_CHECK_LAUNCH();
+    }
+    return GSDD_OK;
+}

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void channel_stats_partial_kernel(const float*
 // the unbiased variance and `momentum` exactly like torch (running = (1-m) running + m stat)
 __global__ void bn_train_finalize_kernel(const double* part, int nblk, int64_t M, int C, const float* weight,
                                          const float* bias, float eps, float momentum, float* running_mean,
-                                         float* running_var, float* scale, float* shift) {
+                                         float* running_var, float* scale, float* shift, float* mean_rstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
@@ -42,6 +42,7 @@ __global__ void bn_train_finalize_kernel(const double* part, int nblk, int64_t M
     const float sc = weight[c] / sqrtf(varf + eps);
     scale[c] = sc;
     shift[c] = bias[c] - meanf * sc;
+    if (mean_rstd != nullptr) { mean_rstd[2 * c] = meanf; mean_rstd[2 * c + 1] = 1.0f / sqrtf(varf + eps); }
     if (running_mean != nullptr) {
         const float unbiased = (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
@@ -130,8 +131,8 @@ extern "C" int64_t gsdd_bn_train_workspace_bytes(int64_t M, int C) {
 }
 
 extern "C" int gsdd_bn_train(const float* x, int64_t M, int C, const float* weight, const float* bias, float eps, float momentum,
-                             float* running_mean, float* running_var, float* scale, float* shift, void* workspace,
-                             int64_t workspace_bytes, void* stream) {
+                             float* running_mean, float* running_var, float* scale, float* shift, float* mean_rstd,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
     GSDD_CHECK_ARG(x && weight && bias && scale && shift && workspace, "null pointer");
     GSDD_CHECK_ARG(M > 0 && C > 0, "bad sizes");
     GSDD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running stats come together");
@@ -141,7 +142,7 @@ extern "C" int gsdd_bn_train(const float* x, int64_t M, int C, const float* weig
     hipLaunchKernelGGL(channel_stats_partial_kernel, dim3(nblk), dim3(256), 0, st, x, M, C, (double*)workspace);
     GSDD_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)workspace, nblk, M, C,
-                       weight, bias, eps, momentum, running_mean, running_var, scale, shift);
+                       weight, bias, eps, momentum, running_mean, running_var, scale, shift, mean_rstd);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

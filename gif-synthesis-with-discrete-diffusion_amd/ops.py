@@ -18,7 +18,7 @@ def taps_tensor(taps, device):
 def gemm(inp, w, out, *, in_dims, out_grid, stride=(1, 1, 1), taps=None, ntaps=1, cin=None, in_pitch=None,
          gather=None, pro=None, ln=None, epi_scale=None, epi_shift=None, bvec=None, rows_per_batch=0, act=ACT_NONE,
          residual=None, out_dims=None, out_step=(1, 1, 1), out_off=(0, 0, 0), out_pitch=None, out_mode=0, cout=None,
-         stream=None):
+         stream=None, _desc_only=False):
     """out[orow(m)][n] = epi(sum_tap sum_c pro(in[src(m,tap)][c]) * w[tap][n][c]).
 
     in_dims = (N, Di, Hi, Wi); out_grid = (Do, Ho, Wo); w: [ntaps][Cout][Cin];
@@ -52,6 +52,8 @@ def gemm(inp, w, out, *, in_dims, out_grid, stride=(1, 1, 1), taps=None, ntaps=1
     d.ood, d.ooh, d.oow = out_off
     d.out_pitch = out_pitch if out_pitch is not None else d.Cout
     d.out_mode = out_mode
+    if _desc_only:
+        return d
     check(lib().gsdd_gemm(C.byref(d), stream_ptr(stream)))
     return out
 
@@ -89,18 +91,22 @@ def nearest_code(z, cb, idx, zq=None, stream=None):
     return idx
 
 
-def bn_train(x, bn, momentum=0.1, update_running=True, stream=None):
-    """Batch statistics of rows x[M][C] -> (scale, shift) for the consuming GEMM's prologue; updates bn's running stats."""
+def bn_train(x, bn, momentum=0.1, update_running=True, want_stats=False, stream=None):
+    """Batch statistics of rows x[M][C] -> (scale, shift) for the consuming GEMM's prologue; updates bn's running stats.
+    want_stats: also return the per-channel (mean, rstd) pairs the backward needs."""
     M, C_ = x.shape
     n = lib().gsdd_bn_train_workspace_bytes(M, C_)
     ws = torch.empty((n // 8,), dtype=torch.float64, device=x.device)
     scale = torch.empty((C_,), dtype=torch.float32, device=x.device)
     shift = torch.empty_like(scale)
     rm, rv = (bn.running_mean, bn.running_var) if update_running else (None, None)
+    mr = torch.empty((C_, 2), dtype=torch.float32, device=x.device) if want_stats else None
     check(lib().gsdd_bn_train(ptr(x), M, C_, ptr(bn.weight.detach()), ptr(bn.bias.detach()), bn.eps, momentum, ptr(rm), ptr(rv),
-                              ptr(scale), ptr(shift), ptr(ws), n, stream_ptr(stream)))
+                              ptr(scale), ptr(shift), ptr(mr), ptr(ws), n, stream_ptr(stream)))
     if update_running:
         bn.num_batches_tracked += 1
+    if want_stats:
+        return (scale, shift), mr
     return scale, shift
 
 
@@ -369,3 +375,41 @@ def adaln_bwd(dtab, t, emb, w, demb, dw, db, stream=None):
 
 def adam(p, g, m, v, lr, beta1, beta2, eps, step, stream=None):
     check(lib().gsdd_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, step, stream_ptr(stream)))
+
+
+# ----------------------------------------------------------------------------- VQ-VAE training-step building blocks
+def conv_wgrad(x, dY, dW, *, in_dims, out_grid, stride=(1, 1, 1), taps=None, ntaps=1, cin, cout, in_pitch=None, pro=None,
+               out_dims=None, out_step=(1, 1, 1), out_off=(0, 0, 0), stream=None):
+    """dW[tap][cout][cin] += sum_m dY[orow(m)] (x) pro(x[src(m,tap)])  (same geometry arguments as the forward gemm)."""
+    d = gemm(x, dW, dW, in_dims=in_dims, out_grid=out_grid, stride=stride, taps=taps, ntaps=ntaps, cin=cin, in_pitch=in_pitch,
+             pro=pro, out_dims=out_dims, out_step=out_step, out_off=out_off, cout=cout, _desc_only=True)
+    check(lib().gsdd_conv_wgrad(C.byref(d), ptr(dY), dY.shape[-1], ptr(dW), stream_ptr(stream)))
+
+
+def bn_relu_bwd(da, x, mean_rstd, bn, dgamma, dbeta, dx_in=None, stream=None):
+    M, C_ = x.shape
+    n = lib().gsdd_bn_relu_bwd_workspace_bytes(M, C_)
+    ws = torch.empty(((n + 7) // 8,), dtype=torch.float64, device=x.device)
+    dx = torch.empty_like(x)
+    check(lib().gsdd_bn_relu_bwd(ptr(da), ptr(x), M, C_, ptr(mean_rstd), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                 ptr(dx_in), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), n, stream_ptr(stream)))
+    return dx
+
+
+def relu_mask(dout, out, stream=None):
+    dpre = torch.empty_like(dout)
+    check(lib().gsdd_relu_mask(ptr(dout), ptr(out), ptr(dpre), dout.numel(), stream_ptr(stream)))
+    return dpre
+
+
+def lincomb(a, b, c, alpha, stream=None):
+    out = torch.empty_like(b)
+    check(lib().gsdd_lincomb(ptr(a), ptr(b), ptr(c), alpha, ptr(out), b.numel(), stream_ptr(stream)))
+    return out
+
+
+def axial_attention_bwd(qkv, datt, dims, C_, n_head, stream=None):
+    N, T, H, W = dims
+    dqkv = torch.empty_like(qkv)
+    check(lib().gsdd_axial_attention_bwd(ptr(qkv), ptr(datt), N, T, H, W, C_, n_head, ptr(dqkv), stream_ptr(stream)))
+    return dqkv

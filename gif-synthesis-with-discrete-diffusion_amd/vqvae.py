@@ -415,7 +415,7 @@ class VQVAE(nn.Module):
     def _forward_train(self, x):
         """Train-mode forward value (videogpt_vq_vae.py:58-72 with Codebook.forward :174-222): BatchNorm batch statistics
         + running-stat update, codebook data-init on the first call, EMA update with all-reduced statistics (C2) and
-        dead-code restart.  No backward exists on the HIP path yet."""
+        dead-code restart.  The backward lives in vqvae_trainer.py."""
         import torch.distributed as dist
         cb = self.codebook
         z, dims = self._encode_rows(x, train=True)
@@ -446,9 +446,10 @@ class VQVAE(nn.Module):
     def forward(self, batch, do_inference=False):
         x = batch["video"].to(self.device).contiguous().float()
         if self.training:
-            if torch.is_grad_enabled():
-                raise NotImplementedError("the VQ-VAE backward pass is not built on the HIP path yet; the train-mode "
-                                          "forward value is available under torch.no_grad()")
+            if torch.is_grad_enabled():                                 # losses carry a grad_fn into the HIP backward
+                from .vqvae_trainer import train_forward
+                recon, commitment, x_recon = train_forward(self, x)
+                return {"pred_data": x_recon, "gt_data": x, "losses": {"recon_loss": recon, "commitment_loss": commitment}}
             out = self._forward_train(x)
             out.pop("encodings")
             out.pop("perplexity")

@@ -102,8 +102,8 @@ int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K,
  * (may be NULL) updated with momentum and the unbiased variance like torch. */
 int64_t gsdd_bn_train_workspace_bytes(int64_t M, int C);
 int gsdd_bn_train(const float* x, int64_t M, int C, const float* weight, const float* bias, float eps, float momentum,
-                  float* running_mean, float* running_var, float* scale, float* shift, void* workspace,
-                  int64_t workspace_bytes, void* stream);
+                  float* running_mean, float* running_var, float* scale, float* shift, float* mean_rstd /* optional [C][2] */,
+                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Codebook EMA (Codebook.forward, videogpt_vq_vae.py:193-214) in two phases so the caller can all-reduce between them
  * (:196-198): phase 0: n_total[K], encode_sum[K][E] from (z rows, idx); phase 1: N, z_avg EMA with `decay`, Laplace-
@@ -117,6 +117,25 @@ int gsdd_codebook_ema(const float* z, const int64_t* idx, int64_t M, int E, int 
  * workspace >= 8 KiB. */
 int gsdd_mse(const float* a, const float* b, int64_t n, float scale, float* out, void* workspace, int64_t workspace_bytes,
              void* stream);
+
+/* ------------------------------------------------------------------ VQ-VAE training step: backward building blocks
+ * (autograd of videogpt_vq_vae.py:102-138, 228-332; data gradients of (transposed) convolutions are gsdd_gemm calls with
+ * transposed weights and mirrored tap tables) */
+/* dW[tap][n][c] += sum_m dY[orow(m)][n] * pro(in[src(m,tap)][c]); geometry / taps / BN+ReLU prologue / dY row addressing
+ * (the output-addressing fields) taken from the forward descriptor; Cout and dy_pitch multiples of 4. */
+int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_pitch, float* dW, void* stream);
+/* a = relu(BatchNorm_train(x)) backward: given da -> dx (= dx_in + ...), dgamma += , dbeta += */
+int64_t gsdd_bn_relu_bwd_workspace_bytes(int64_t M, int C);
+int gsdd_bn_relu_bwd(const float* da, const float* x, int64_t M, int C, const float* mean_rstd, const float* gamma,
+                     const float* beta, const float* dx_in, float* dx, float* dgamma, float* dbeta, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+/* dpre = dout * [out > 0] */
+int gsdd_relu_mask(const float* dout, const float* out, float* dpre, int64_t n, void* stream);
+/* out = (a ? a : 0) + alpha * (b - c) */
+int gsdd_lincomb(const float* a, const float* b, const float* c, float alpha, float* out, int64_t n, void* stream);
+/* backward of gsdd_axial_attention: datt rows [M][3C] -> dqkv rows [M][9C] */
+int gsdd_axial_attention_bwd(const float* qkv, const float* datt, int N, int T, int H, int W, int C, int n_head, float* dqkv,
+                             void* stream);
 
 /* ------------------------------------------------------------------ D3PM denoiser pieces
  * x[b][l][:] = emb[tok[b][l]] + pos[l]   (DalleMaskImageEmbedding.forward, dalle_mask_image_embedding.py:59-79;

@@ -165,7 +165,8 @@ def forward_eval(x, sd, cfg):
             "encodings": idx}
 
 
-# ----------------------------------------------------------------------------- train-mode forward (no grad)
+# ----------------------------------------------------------------------------- train-mode forward (autograd-friendly:
+# tests differentiate recon_loss + commitment_loss through it for the gradient reference)
 def bn_train(x, sd, p, out_sd, eps=1e-5, momentum=0.1):
     """nn.BatchNorm3d in train mode: batch statistics, running stats updated with the unbiased variance."""
     rm, rv = sd[p + "running_mean"].clone(), sd[p + "running_var"].clone()
@@ -203,7 +204,7 @@ def forward_train(x, sd, cfg, perm):
     idx, _ = nearest_code(z, E)
     flat = z.permute(0, 2, 3, 4, 1).reshape(-1, z.shape[1])
     emb = F.embedding(idx, E).permute(0, 4, 1, 2, 3).contiguous()
-    commitment = 0.25 * F.mse_loss(z, emb)
+    commitment = 0.25 * F.mse_loss(z, emb.detach())                   # :190
     onehot = F.one_hot(idx.view(-1), K).type_as(flat)
     n_total = onehot.sum(dim=0)
     encode_sum = flat.t() @ onehot
@@ -217,7 +218,7 @@ def forward_train(x, sd, cfg, perm):
     usage = (N.view(K, 1) >= 1).float()
     newE = newE * usage + k_rand * (1 - usage)
     new.update({"codebook.N": N, "codebook.z_avg": z_avg, "codebook.embeddings": newE})
-    emb_st = (emb - z) + z
+    emb_st = (emb - z).detach() + z                                   # straight-through estimator (:216)
     h = same_pad_conv3d(emb_st, sd["post_vq_conv.conv.weight"], sd["post_vq_conv.conv.bias"], (1, 1, 1))
     h = _res_stack_train(h, sd, "decoder.res_stack.", cfg["n_res_layers"], new)
     strides = conv_strides(cfg["downsample"])

@@ -1,0 +1,140 @@
+"""VQ-VAE training step on the HIP path: gradient of recon_loss + commitment_loss w.r.t. every parameter against
+torch.autograd of the CPU oracle's train-mode forward (oracle/vqvae.py::forward_train, itself pinned to the reference by
+tests/golden/vqvae_train_ds188.npz), the autograd bridge behind VQVAE.forward, and one Adam step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gsdd_amd
+    assert torch.cuda.is_available()
+    gsdd_amd.lib()
+    return gsdd_amd
+
+
+def build_vqvae(G, sd, cfg):
+    m = G.VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"], cfg["downsample"],
+                cfg["sequence_length"], cfg["resolution"])
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.codebook._need_init = False
+    return m
+
+
+def oracle_grads(x, sd, cfg, perm, w_recon=1.0, w_commit=1.0):
+    from oracle import vqvae as ov
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and not k.startswith("codebook.")
+             and "running_" not in k]
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
+    out, _ = ov.forward_train(x, leaf, cfg, perm)
+    loss = w_recon * out["losses"]["recon_loss"] + w_commit * out["losses"]["commitment_loss"]
+    loss.backward()
+    return out, {k: (leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])) for k in names}
+
+
+def case(G, golden, name):
+    """-> (x, sd, cfg, perm)"""
+    if name == "train_ds188":
+        import os
+        from tests.conftest import GOLDEN
+        z = np.load(os.path.join(GOLDEN, "vqvae_train_ds188.npz"))
+        sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+        cfg = {k[4:]: (z[k].tolist() if z[k].ndim else z[k].item()) for k in z.files if k.startswith("cfg_")}
+        return torch.from_numpy(z["x"]), sd, cfg, z["perm"][0]
+    if name == "ds244":
+        sd, a, cfg = golden("vqvae_ds244")
+        rng = np.random.default_rng(3)
+        return torch.from_numpy(a["x"]), sd, cfg, rng.permutation(32)
+    # random-initialised wider net: channel counts that are not multiples of the 64-wide tiles, stride-1 time axis in layer 2
+    cfg = dict(embedding_dim=12, n_codes=40, n_hiddens=48, n_res_layers=2, downsample=[2, 4, 4], sequence_length=4, resolution=16)
+    torch.manual_seed(11)
+    m = G.VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"], cfg["downsample"],
+                cfg["sequence_length"], cfg["resolution"])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in sd:                                           # non-trivial BN affine parameters
+        if k.endswith(".weight") and sd[k].ndim == 1:
+            sd[k] = 1.0 + 0.2 * torch.randn_like(sd[k])
+        if k.endswith(".bias") and sd[k].ndim == 1 and ("block" in k or "res_stack" in k):
+            sd[k] = 0.1 * torch.randn_like(sd[k])
+    sd["codebook.embeddings"] = 0.3 * torch.randn(cfg["n_codes"], cfg["embedding_dim"])
+    sd["codebook.z_avg"] = sd["codebook.embeddings"].clone()
+    sd["codebook.N"] = torch.ones(cfg["n_codes"])
+    x = torch.rand(3, 3, 4, 16, 16) - 0.5
+    return x, sd, cfg, np.random.default_rng(5).permutation(3 * 2 * 4 * 4)
+
+
+def compare(got, want, tol=2e-3):
+    assert set(got) == set(want), set(got) ^ set(want)
+    gmax = max(w.abs().max().item() for w in want.values())
+    worst = ("", 0.0)
+    for k, w in want.items():
+        gk = got[k].detach().cpu()
+        assert gk.shape == w.shape, (k, gk.shape, w.shape)
+        # per-channel constants in front of a train-mode BatchNorm (conv_last bias, the last block's fc biases) have a
+        # mathematically zero gradient: both sides are rounding noise there, hence the floor
+        scale = max(w.abs().max().item(), 1e-3 * gmax)
+        err = (gk - w).abs().max().item() / scale
+        if err > worst[1]:
+            worst = (k, err)
+        assert err < tol, f"{k}: relative max error {err:.3e} (|g|max {scale:.3e})"
+    print("worst relative gradient error:", worst)
+
+
+@pytest.mark.parametrize("name", ["train_ds188", "ds244", "wide"])
+def test_vqvae_gradients_match_autograd_of_oracle(G, golden, name):
+    from gsdd_amd.vqvae_trainer import VQVAETrainer
+    x, sd, cfg, perm = case(G, golden, name)
+    out, want = oracle_grads(x, sd, cfg, perm)
+    m = build_vqvae(G, sd, cfg)
+    pt = torch.from_numpy(np.asarray(perm))
+    m.perm_source = lambda n: pt
+    losses, got = VQVAETrainer(m).loss_and_grads(x.cuda())
+    np.testing.assert_allclose(losses["recon_loss"].item(), out["losses"]["recon_loss"].item(), rtol=1e-4)
+    np.testing.assert_allclose(losses["commitment_loss"].item(), out["losses"]["commitment_loss"].item(), rtol=1e-4)
+    compare(got, want)
+
+
+def test_vqvae_forward_backward_through_autograd_bridge(G, golden):
+    """The reference's Lightning loop calls loss.backward() on mean(commitment + recon) (text_motion_model.py:93-144,
+    loss_func.py:10-14): VQVAE.forward in train mode must hand back losses whose backward fills every .grad; uneven loss
+    weights exercise the (g_recon, g_commit) plumbing."""
+    x, sd, cfg, perm = case(G, golden, "train_ds188")
+    _, want = oracle_grads(x, sd, cfg, perm, w_recon=0.7, w_commit=3.0)
+    m = build_vqvae(G, sd, cfg)
+    pt = torch.from_numpy(np.asarray(perm))
+    m.perm_source = lambda n: pt
+    out = m({"video": x.cuda()})
+    assert out["losses"]["recon_loss"].requires_grad and not out["pred_data"].requires_grad
+    (0.7 * out["losses"]["recon_loss"] + 3.0 * out["losses"]["commitment_loss"]).backward()
+    got = {k: p.grad for k, p in m.named_parameters()}
+    assert all(g is not None for g in got.values())
+    compare(got, want)
+
+
+def test_vqvae_adam_step_matches_torch(G, golden):
+    from gsdd_amd.vqvae_trainer import VQVAETrainer
+    x, sd, cfg, perm = case(G, golden, "train_ds188")
+    _, want_g = oracle_grads(x, sd, cfg, perm)
+    params = {k: torch.nn.Parameter(sd[k].clone()) for k in want_g}
+    opt = torch.optim.Adam(list(params.values()), lr=4e-4, betas=(0.5, 0.999))
+    for k, prm in params.items():
+        prm.grad = want_g[k]
+    opt.step()
+    m = build_vqvae(G, sd, cfg)
+    pt = torch.from_numpy(np.asarray(perm))
+    m.perm_source = lambda n: pt
+    VQVAETrainer(m, lr=4e-4, betas=(0.5, 0.999)).step(x.cuda())
+    got = dict(m.named_parameters())
+    gmax = max(v.abs().max().item() for v in want_g.values())
+    for k, prm in params.items():
+        if want_g[k].abs().max().item() < 1e-4 * gmax:
+            continue
+        d_ref = prm.detach() - sd[k]
+        d_got = got[k].detach().cpu() - sd[k]
+        big = want_g[k].abs() > 1e-2 * want_g[k].abs().max()
+        assert torch.allclose(d_got[big], d_ref[big], atol=4e-6, rtol=2e-2), k
+    assert m._packed is None
