@@ -404,6 +404,8 @@ class VQVAE(nn.Module):
         y = self._tile(z)
         src = getattr(self, "perm_source", None)
         perm = (src(y.shape[0]) if src is not None else torch.randperm(y.shape[0], device=z.device)).to(z.device)
+        if src is not None and (perm.numel() < self.n_codes or int(perm.max()) >= y.shape[0] or int(perm.min()) < 0):
+            raise GsddError(f"perm_source must return at least {self.n_codes} indices below {y.shape[0]}")
         perm = perm[: self.n_codes].long().contiguous()
         if dist.is_available() and dist.is_initialized():
             rows = y[perm].contiguous()

@@ -24,8 +24,8 @@ class TextMotionModel(BaseModel):
         out = self.generator_step(batch)
         losses = out["losses"]
         total = torch.mean(losses["commitment_loss"] + losses["recon_loss"])          # compute_dummy, loss_func.py:10-14
-        self.log_dict({f"recon/{split}": float(losses["recon_loss"]), f"commitment/{split}": float(losses["commitment_loss"]),
-                       f"total/{split}": float(total)})
+        self.log_dict({f"recon/{split}": float(losses["recon_loss"].detach()), f"commitment/{split}": float(losses["commitment_loss"].detach()),
+                       f"total/{split}": float(total.detach())})
         return total
 
     def configure_optimizers(self):

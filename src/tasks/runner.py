@@ -38,7 +38,7 @@ def train(cfg):
     for epoch in range(cfg.trainer.get("max_epochs", 1)):
         for i, batch in enumerate(datamodule.train_dataloader()):
             loss = model.training_step(batch, i)        # stage 2: a full optimiser step on the HIP path
-            if loss.requires_grad:                      # (stage 1 / VQ-VAE: backward not built on the HIP path yet)
+            if loss.requires_grad:                      # stage 1: VQVAE.forward hands back losses whose grad_fn is the HIP backward
                 for o in opts:
                     o.zero_grad()
                 loss.backward()

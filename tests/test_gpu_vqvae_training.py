@@ -138,3 +138,58 @@ def test_vqvae_adam_step_matches_torch(G, golden):
         big = want_g[k].abs() > 1e-2 * want_g[k].abs().max()
         assert torch.allclose(d_got[big], d_ref[big], atol=4e-6, rtol=2e-2), k
     assert m._packed is None
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import gsdd_amd
+    from gsdd_amd.vqvae_trainer import VQVAETrainer
+    from tests.conftest import load_golden
+    dist.init_process_group("gloo")                  # rehearsal backend: both ranks share the box's single GPU
+    torch.cuda.set_device(0)
+    x, sd, cfg, perm = case(gsdd_amd, load_golden, "train_ds188")
+    m = build_vqvae(gsdd_amd, sd, cfg)
+    pt = torch.from_numpy(np.random.default_rng(7).permutation(64))     # one clip per rank: 64 latent rows
+    m.perm_source = lambda n: pt
+    tr = VQVAETrainer(m)
+    _, g = tr.loss_and_grads(x[rank:rank + 1].cuda())
+    g = tr.all_reduce_grads(g)
+    tr2 = VQVAETrainer(build_vqvae(gsdd_amd, sd, cfg))
+    tr2.vq.perm_source = lambda n: pt
+    tr2.step(x[rank:rank + 1].cuda())                 # the full step (codebook collectives + all-reduce + Adam) must run
+    cb = tr2.vq.codebook.embeddings.detach().cpu().numpy()
+    q.put((rank, {k: v.cpu().numpy() for k, v in g.items()}, cb))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vqvae_two_rank_data_parallel_gradients(G, golden):
+    """BatchNorm statistics are rank-local in the reference (sync_batchnorm off), so the data-parallel gradient is the mean of the
+    per-rank gradients; the codebook (EMA statistics all-reduced, restart rows broadcast from rank 0) must end up identical on
+    both ranks."""
+    import os
+    import torch.multiprocessing as mp
+    from gsdd_amd.vqvae_trainer import VQVAETrainer
+    x, sd, cfg, perm = case(G, golden, "train_ds188")
+    pt = torch.from_numpy(np.random.default_rng(7).permutation(64))
+    per_rank = []
+    for r in range(2):
+        m = build_vqvae(G, sd, cfg)
+        m.perm_source = lambda n: pt
+        per_rank.append(VQVAETrainer(m).loss_and_grads(x[r:r + 1].cuda())[1])
+    want = {k: 0.5 * (per_rank[0][k] + per_rank[1][k]).cpu() for k in per_rank[0]}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _, g, _ in res:
+        compare({k: torch.from_numpy(v) for k, v in g.items()}, want, tol=1e-4)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
