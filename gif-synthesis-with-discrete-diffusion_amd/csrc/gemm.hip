@@ -44,9 +44,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     const int bn0 = blockIdx.y * BN;
     const int kq = tid & 7, r0 = tid >> 3;
 
-    // ---- per-thread staged rows of the activation operand
-    int ti0[4], hi0[4], wi0[4];
-    int64_t nb[4];
+    // ---- per-thread staged rows of the activation operand (row index and tap-free coordinates, all 32-bit)
+    int ti0[4], hi0[4], wi0[4], rbase[4];
     bool rvalid[4];
     float mu[4], rs[4];
     int64_t sel[4];
@@ -56,15 +55,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
         rvalid[j] = m < M;
         const uint32_t mm = rvalid[j] ? (uint32_t)m : 0u;          // M < 2^31 (checked on the host)
         if (d.gather != nullptr) {
-            nb[j] = rvalid[j] ? d.gather[mm] : 0;
+            rbase[j] = rvalid[j] ? (int)d.gather[mm] : 0;
             ti0[j] = hi0[j] = wi0[j] = 0;
         } else {
             uint32_t q = mm;
             const uint32_t wo = q % (uint32_t)d.Wo; q /= (uint32_t)d.Wo;
             const uint32_t ho = q % (uint32_t)d.Ho; q /= (uint32_t)d.Ho;
             const uint32_t to = q % (uint32_t)d.Do; q /= (uint32_t)d.Do;
-            nb[j] = q;
             ti0[j] = (int)to * d.sd; hi0[j] = (int)ho * d.sh; wi0[j] = (int)wo * d.sw;
+            rbase[j] = (((int)q * d.Di + ti0[j]) * d.Hi + hi0[j]) * d.Wi + wi0[j];      // input rows < 2^31 (host check)
         }
         mu[j] = 0.f; rs[j] = 1.f; sel[j] = 0;
         if (d.ln_stats != nullptr) {
@@ -75,59 +74,74 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
 
     const int cchunks = (d.Cin + BK - 1) / BK;
     const int nchunks = d.ntaps * cchunks;
+    const bool has_pro = d.pro_scale != nullptr;
+    const float* pro_s = has_pro ? d.pro_scale : d.w;          // always-dereferenceable pointers: the loads below are
+    const float* pro_b = has_pro ? d.pro_shift : d.w;          // unconditional so that nothing waits on them before the MFMAs
 
-    float4 ra[4], rb[BJ];
+    // Global loads of chunk i+1 are issued before the MFMAs of chunk i and consumed after them.  They are branch-free
+    // (out-of-range rows / channels read a clamped, valid address and are zeroed when staged into LDS): a load under an
+    // exec-masked branch makes the compiler wait for it on the spot, which serialises memory latency with the MFMAs.
+    float4 ra[4], rb[BJ], ps, pb;
+    unsigned okbits = 0;
+    int cc = 0;
     auto load_chunk = [&](int chunk) {
         const int tap = chunk / cchunks;
         const int c = (chunk - tap * cchunks) * BK + 4 * kq;
         const bool cvalid = c < d.Cin;
+        cc = cvalid ? c : 0;
         int dt = 0, dh = 0, dw = 0;
         if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
-        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.pro_scale != nullptr && cvalid) {
-            ps = *reinterpret_cast<const float4*>(d.pro_scale + c);
-            pb = *reinterpret_cast<const float4*>(d.pro_shift + c);
-        }
+        const int tapoff = (dt * d.Hi + dh) * d.Wi + dw;
+        ps = *reinterpret_cast<const float4*>(pro_s + cc);
+        pb = *reinterpret_cast<const float4*>(pro_b + cc);
+        okbits = 0;
+        const float* pa[4];
+        const float* pw[BJ];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool ok = rvalid[j] && cvalid;
-            int64_t row;
-            if (d.gather != nullptr) {
-                row = nb[j];
-            } else {
-                const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
-                ok = ok && (unsigned)ti < (unsigned)d.Di && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
-                row = ((nb[j] * d.Di + ti) * d.Hi + hi) * (int64_t)d.Wi + wi;
-            }
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(d.in + row * d.in_pitch + c);
-                if (d.pro_scale != nullptr) {
-                    v.x = fmaxf(fmaf(v.x, ps.x, pb.x), 0.f); v.y = fmaxf(fmaf(v.y, ps.y, pb.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, ps.z, pb.z), 0.f); v.w = fmaxf(fmaf(v.w, ps.w, pb.w), 0.f);
-                }
-                if (d.ln_stats != nullptr) {
-                    const float4 g = *reinterpret_cast<const float4*>(d.ln_gamma + sel[j] * d.ln_stride + c);
-                    const float4 bt = *reinterpret_cast<const float4*>(d.ln_beta + sel[j] * d.ln_stride + c);
-                    v.x = (v.x - mu[j]) * rs[j] * g.x + bt.x; v.y = (v.y - mu[j]) * rs[j] * g.y + bt.y;
-                    v.z = (v.z - mu[j]) * rs[j] * g.z + bt.z; v.w = (v.w - mu[j]) * rs[j] * g.w + bt.w;
-                }
-            }
-            ra[j] = v;
+            const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
+            const bool ok = rvalid[j] & cvalid & ((unsigned)ti < (unsigned)d.Di) & ((unsigned)hi < (unsigned)d.Hi) &
+                            ((unsigned)wi < (unsigned)d.Wi);
+            const int row = ok ? rbase[j] + tapoff : 0;
+            pa[j] = d.in + ((int64_t)row * d.in_pitch + cc);
+            okbits |= (ok ? 1u : 0u) << j;
         }
+        const int wrow0 = tap * d.Cout;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int n = bn0 + r0 + 32 * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < d.Cout && cvalid) v = *reinterpret_cast<const float4*>(d.w + ((int64_t)tap * d.Cout + n) * d.Cin + c);
-            rb[j] = v;
+            const bool ok = (n < d.Cout) & cvalid;
+            pw[j] = d.w + (uint32_t)((wrow0 + (ok ? n : 0)) * d.Cin + cc);           // weights hold < 2^31 elements (host check)
+            okbits |= (ok ? 1u : 0u) << (8 + j);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j]);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const float4*>(pw[j]);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = ra[j];
+        for (int j = 0; j < 4; ++j) {
+            float4 v = ra[j];
+            if (has_pro) {
+                v.x = fmaxf(fmaf(v.x, ps.x, pb.x), 0.f); v.y = fmaxf(fmaf(v.y, ps.y, pb.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, ps.z, pb.z), 0.f); v.w = fmaxf(fmaf(v.w, ps.w, pb.w), 0.f);
+            }
+            if (d.ln_stats != nullptr) {
+                const float4 g = *reinterpret_cast<const float4*>(d.ln_gamma + sel[j] * d.ln_stride + cc);
+                const float4 bt = *reinterpret_cast<const float4*>(d.ln_beta + sel[j] * d.ln_stride + cc);
+                v.x = (v.x - mu[j]) * rs[j] * g.x + bt.x; v.y = (v.y - mu[j]) * rs[j] * g.y + bt.y;
+                v.z = (v.z - mu[j]) * rs[j] * g.z + bt.z; v.w = (v.w - mu[j]) * rs[j] * g.w + bt.w;
+            }
+            if (!((okbits >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = v;
+        }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = rb[j];
+        for (int j = 0; j < BJ; ++j) {
+            float4 v = rb[j];
+            if (!((okbits >> (8 + j)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = v;
+        }
     };
 
     f32x16 acc[2][NT];
@@ -289,6 +303,8 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
     GSDD_CHECK_ARG(d->out_mode != 0 || d->out_pitch >= d->Cout, "out_pitch too small");
     const int64_t M = (int64_t)d->N * d->Do * d->Ho * d->Wo;
     GSDD_CHECK_ARG(M < (1ll << 31), "more than 2^31 rows");
+    GSDD_CHECK_ARG(d->gather != nullptr || (int64_t)d->N * d->Di * d->Hi * d->Wi < (1ll << 31), "more than 2^31 input rows");
+    GSDD_CHECK_ARG((int64_t)d->ntaps * d->Cout * d->Cin < (1ll << 31), "more than 2^31 weight elements");
     hipStream_t st = (hipStream_t)stream;
     const unsigned gx = (unsigned)((M + BM - 1) / BM);
     if (d->Cout > 64) {

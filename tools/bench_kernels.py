@@ -77,6 +77,75 @@ def main():
         o = torch.empty((M, K), device=dev)
         ms = timeit(lambda: ops.d3pm_logits(x, g, bt, w, b, o))
         print(f"logits kernel 64->{K}: {ms:.3f} ms  {2.0 * M * D * K / ms / 1e9:.1f} TFLOP/s  {4.0 * M * K / ms / 1e6:.0f} GB/s written")
+    if "conv" in which:
+        # VQ-VAE shapes at C2 (C = 256), batch 8
+        from gsdd_amd.vqvae import conv_taps, convT_phases
+        Bc, C_ = 8, 256
+        f = dict(dtype=torch.float32, device=dev)
+
+        def report(name, ms, fl):
+            print(f"{name:34s}: {ms:8.3f} ms  {fl / ms / 1e9:6.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)", flush=True)
+        Mrows = Bc * 16 * 32 * 32
+        a = torch.randn((Mrows, 4096), **f); w = torch.randn((1, C_, 4096), **f) * 0.02; o = torch.empty((Mrows, C_), **f)
+        ms = timeit(lambda: ops.gemm(a, w, o, in_dims=(1, 1, 1, Mrows), out_grid=(1, 1, Mrows)), iters=5)
+        report("plain gemm M=131072 K=4096 N=256", ms, 2.0 * Mrows * 4096 * C_)
+        del a
+        # conv1: (16,64,64)x256 -> (16,32,32)x256, k4 s(1,2,2)
+        x = torch.randn((Bc * 16 * 64 * 64, C_), **f)
+        taps = ops.taps_tensor(conv_taps((4, 4, 4), (1, 2, 2), (2, 1, 1)), dev)
+        w = torch.randn((64, C_, C_), **f) * 0.02
+        o = torch.empty((Mrows, C_), **f)
+        bias = torch.randn((C_,), **f)
+        ms = timeit(lambda: ops.gemm(x, w, o, in_dims=(Bc, 16, 64, 64), out_grid=(16, 32, 32), stride=(1, 2, 2), taps=taps, ntaps=64,
+                                     epi_shift=bias, act=ops.ACT_RELU), iters=5)
+        report("conv1 k4 s(1,2,2) 256->256", ms, 2.0 * Mrows * 64 * C_ * C_)
+        dW = torch.zeros_like(w)
+        dY = torch.randn((Mrows, C_), **f)
+        ms = timeit(lambda: ops.conv_wgrad(x, dY, dW, in_dims=(Bc, 16, 64, 64), out_grid=(16, 32, 32), stride=(1, 2, 2), taps=taps,
+                                           ntaps=64, cin=C_, cout=C_), iters=5)
+        report("conv1 wgrad", ms, 2.0 * Mrows * 64 * C_ * C_)
+        del x, dY
+        # res-block conv3: 27 taps 256 -> 128 with BN+ReLU prologue on the latent grid
+        Ml = Bc * 16 * 16 * 16
+        h = torch.randn((Ml, C_), **f)
+        w3 = torch.randn((27, C_ // 2, C_), **f) * 0.02
+        t3 = ops.taps_tensor(conv_taps((3, 3, 3), (1, 1, 1), (1, 1, 1)), dev)
+        pro = (torch.rand((C_,), **f) + 0.5, torch.randn((C_,), **f) * 0.1)
+        o3 = torch.empty((Ml, C_ // 2), **f)
+        ms = timeit(lambda: ops.gemm(h, w3, o3, in_dims=(Bc, 16, 16, 16), out_grid=(16, 16, 16), taps=t3, ntaps=27, pro=pro))
+        report("res conv3 27 taps 256->128 (pro)", ms, 2.0 * Ml * 27 * C_ * C_ // 2)
+        wq = torch.randn((1, 9 * C_, C_), **f) * 0.02
+        oq = torch.empty((Ml, 9 * C_), **f)
+        ms = timeit(lambda: ops.gemm(h, wq, oq, in_dims=(Bc, 16, 16, 16), out_grid=(16, 16, 16), pro=pro))
+        report("res qkv 1x1 256->2304 (pro)", ms, 2.0 * Ml * 9 * C_ * C_)
+        # convT1 phases: (16,32,32) -> (16,64,64), 4 phases x 16 taps
+        xin = torch.randn((Mrows, C_), **f)
+        out = torch.empty((Bc * 16 * 64 * 64, C_), **f)
+        phases = convT_phases((4, 4, 4), (1, 2, 2), (2, 1, 1))
+        pw = [(ph, torch.randn((len(ks), C_, C_), **f) * 0.02, ops.taps_tensor(offs, dev)) for ph, ks, offs in phases]
+
+        def convT():
+            for ph, wph, tp in pw:
+                ops.gemm(xin, wph, out, in_dims=(Bc, 16, 32, 32), out_grid=(16, 32, 32), taps=tp, ntaps=wph.shape[0], epi_shift=bias,
+                         act=ops.ACT_RELU, out_dims=(16, 64, 64), out_step=(1, 2, 2), out_off=ph)
+        ms = timeit(convT, iters=5)
+        report("convT1 (4 phases x 16 taps)", ms, 2.0 * Mrows * 64 * C_ * C_)
+        # last convT: 256 -> 3, NCDHW output
+        xin2 = out
+        out3 = torch.empty((Bc, 3, 16, 128, 128), **f)
+        pw3 = [(ph, torch.randn((len(ks), 3, C_), **f) * 0.02, ops.taps_tensor(offs, dev)) for ph, ks, offs in phases]
+        b3 = torch.randn((3,), **f)
+
+        def convT3():
+            for ph, wph, tp in pw3:
+                ops.gemm(xin2, wph, out3, in_dims=(Bc, 16, 64, 64), out_grid=(16, 64, 64), taps=tp, ntaps=wph.shape[0], epi_shift=b3,
+                         out_dims=(16, 128, 128), out_step=(1, 2, 2), out_off=ph, out_mode=1)
+        ms = timeit(convT3, iters=5)
+        report("convT2 256->3 (4 phases x 16 taps)", ms, 2.0 * Bc * 16 * 64 * 64 * 64 * C_ * 3)
+        zz = torch.randn((Ml, 128), **f); cb = torch.randn((4096, 128), **f)
+        idx = torch.empty((Ml,), dtype=torch.int64, device=dev)
+        ms = timeit(lambda: ops.nearest_code(zz, cb, idx))
+        report("nearest_code 32768 x 4096 x 128", ms, 2.0 * Ml * 4096 * 128)
     if "step" in which:
         Bs = B2 // 2
         logits = torch.randn((M, K), device=dev)
