@@ -10,11 +10,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------ conv weight gradient
 //   dW[tap][n][c] += sum_m dY[orow(m)][n] * pro(X[src(m,tap)][c])
-// grid: (row slabs, n-tiles * c-tiles, taps); 128 rows per slab iteration, 64x64 output tile, 4 waves (32x32 quadrants)
+// grid: (row slabs, n-tiles * c-tiles, taps); 128 rows per slab, 64x64 output tile, 4 waves (32x32 quadrants) contracting over
+// the slab's rows on v_mfma_f32_32x32x2_f32.  Per slab: 128 threads decode one row each (source row of this tap or -1, output
+// row) into LDS, every thread then issues its 16 branch-free float4 loads of slab s+1 before the 64 MFMAs of slab s and stages
+// them into the (single) LDS tile afterwards, so global latency hides under the MFMAs.
 constexpr int CW_ROWS = 128;
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const gsdd_gemm_desc d, const float* dY, int dy_pitch, float* dW,
-                                                         const int64_t M, int slabs, int ctiles) {
-    __shared__ float sy[CW_ROWS][64], sx[CW_ROWS][64];
+struct CwSmem {
+    float y[CW_ROWS][64];
+    float x[CW_ROWS][64];
+    int src[2][CW_ROWS];
+    int dst[2][CW_ROWS];
+};
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const gsdd_gemm_desc d, const float* dY, int dy_pitch, float* dW,
+                                                            const int64_t M, int slabs, int ctiles) {
+    extern __shared__ __attribute__((aligned(16))) char cw_raw[];
+    CwSmem& sm = *reinterpret_cast<CwSmem*>(cw_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int n0 = (blockIdx.y / ctiles) * 64, c0 = (blockIdx.y % ctiles) * 64;
@@ -24,49 +34,103 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gsdd_gemm_desc d,
     if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
     const bool linear_rows = (d.oD == d.Do && d.oH == d.Ho && d.oW == d.Wo && d.osd == 1 && d.osh == 1 && d.osw == 1 &&
                               d.ood == 0 && d.ooh == 0 && d.oow == 0);
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int sl = 0; sl < slabs; ++sl) {
-        const int64_t r0 = ((int64_t)blockIdx.x * slabs + sl) * CW_ROWS;
-        if (r0 >= M) break;
-        __syncthreads();
-        for (int i = tid; i < CW_ROWS * 16; i += 256) {
-            const int r = i >> 4, c = (i & 15) * 4;
-            float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
-            const int64_t m = r0 + r;
+    const int64_t slab0 = (int64_t)blockIdx.x * slabs;
+    int nsl = (int)((M - slab0 * CW_ROWS + CW_ROWS - 1) / CW_ROWS);
+    nsl = nsl < slabs ? nsl : slabs;
+    if (nsl <= 0) return;
+
+    const int c4 = (tid & 15) * 4, rr = tid >> 4;
+    const bool cy_ok = n0 + c4 < d.Cout, cx_ok = c0 + c4 < d.Cin;
+    const int ycol = cy_ok ? n0 + c4 : 0, xcol = cx_ok ? c0 + c4 : 0;
+    const bool has_pro = d.pro_scale != nullptr;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_pro) { ps = *reinterpret_cast<const float4*>(d.pro_scale + xcol); pb = *reinterpret_cast<const float4*>(d.pro_shift + xcol); }
+
+    auto decode = [&](int sl) {                       // one row per thread (threads 0..127)
+        if (tid < CW_ROWS) {
+            const int64_t m = (slab0 + sl) * CW_ROWS + tid;
+            int src = -1, dst = -1;
             if (m < M) {
                 uint32_t q = (uint32_t)m;
                 const uint32_t wo = q % (uint32_t)d.Wo; q /= (uint32_t)d.Wo;
                 const uint32_t ho = q % (uint32_t)d.Ho; q /= (uint32_t)d.Ho;
                 const uint32_t to = q % (uint32_t)d.Do; q /= (uint32_t)d.Do;
-                const int64_t nb = q;
-                if (n0 + c < d.Cout) {
-                    int64_t orow = m;
-                    if (!linear_rows)
-                        orow = ((nb * d.oD + ((int64_t)to * d.osd + d.ood)) * d.oH + ((int)ho * d.osh + d.ooh)) * (int64_t)d.oW +
-                               ((int)wo * d.osw + d.oow);
-                    vy = *reinterpret_cast<const float4*>(dY + orow * dy_pitch + n0 + c);
-                }
+                dst = (int)m;
+                if (!linear_rows)
+                    dst = (((int)q * d.oD + ((int)to * d.osd + d.ood)) * d.oH + ((int)ho * d.osh + d.ooh)) * d.oW + ((int)wo * d.osw + d.oow);
                 const int ti = (int)to * d.sd + dt, hi = (int)ho * d.sh + dh, wi = (int)wo * d.sw + dw;
-                if (c0 + c < d.Cin && (unsigned)ti < (unsigned)d.Di && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
-                    const int64_t row = ((nb * d.Di + ti) * d.Hi + hi) * (int64_t)d.Wi + wi;
-                    vx = *reinterpret_cast<const float4*>(d.in + row * d.in_pitch + c0 + c);
-                    if (d.pro_scale != nullptr) {
-                        const float4 ps = *reinterpret_cast<const float4*>(d.pro_scale + c0 + c);
-                        const float4 pb = *reinterpret_cast<const float4*>(d.pro_shift + c0 + c);
-                        vx.x = fmaxf(fmaf(vx.x, ps.x, pb.x), 0.f); vx.y = fmaxf(fmaf(vx.y, ps.y, pb.y), 0.f);
-                        vx.z = fmaxf(fmaf(vx.z, ps.z, pb.z), 0.f); vx.w = fmaxf(fmaf(vx.w, ps.w, pb.w), 0.f);
+                if ((unsigned)ti < (unsigned)d.Di && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
+                    src = (((int)q * d.Di + ti) * d.Hi + hi) * d.Wi + wi;
+            }
+            sm.src[sl & 1][tid] = src;
+            sm.dst[sl & 1][tid] = dst;
+        }
+    };
+    float4 vy[8], vx[8];
+    unsigned okbits = 0;
+    auto issue = [&](int sl) {
+        okbits = 0;
+        const float* py[8];
+        const float* px[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int src = sm.src[sl & 1][rr + 16 * k], dst = sm.dst[sl & 1][rr + 16 * k];
+            const bool oky = (dst >= 0) & cy_ok, okx = (src >= 0) & cx_ok;
+            py[k] = dY + ((int64_t)(oky ? dst : 0) * dy_pitch + ycol);
+            px[k] = d.in + ((int64_t)(okx ? src : 0) * d.in_pitch + xcol);
+            okbits |= ((oky ? 1u : 0u) << k) | ((okx ? 1u : 0u) << (8 + k));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vy[k] = *reinterpret_cast<const float4*>(py[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vx[k] = *reinterpret_cast<const float4*>(px[k]);
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float4 y = vy[k], x = vx[k];
+            if (has_pro) {
+                x.x = fmaxf(fmaf(x.x, ps.x, pb.x), 0.f); x.y = fmaxf(fmaf(x.y, ps.y, pb.y), 0.f);
+                x.z = fmaxf(fmaf(x.z, ps.z, pb.z), 0.f); x.w = fmaxf(fmaf(x.w, ps.w, pb.w), 0.f);
+            }
+            if (!((okbits >> k) & 1u)) y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!((okbits >> (8 + k)) & 1u)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sm.y[rr + 16 * k][c4]) = y;
+            *reinterpret_cast<float4*>(&sm.x[rr + 16 * k][c4]) = x;
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    decode(0);
+    __syncthreads();
+    issue(0);
+    stage();
+    for (int sl = 0; sl < nsl; ++sl) {
+        const bool more = sl + 1 < nsl;
+        if (more) decode(sl + 1);
+        __syncthreads();                               // tile of slab sl staged, row table of slab sl+1 visible
+        if (more) issue(sl + 1);
+        {                                              // 64 k-steps, operands fetched one batch of 8 ahead of the MFMAs
+            float yb[2][8], xb[2][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { yb[0][u] = sm.y[2 * u + lh][wn * 32 + li]; xb[0][u] = sm.x[2 * u + lh][wk * 32 + li]; }
+#pragma unroll
+            for (int b8 = 0; b8 < 8; ++b8) {
+                if (b8 + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        yb[(b8 + 1) & 1][u] = sm.y[2 * (8 * (b8 + 1) + u) + lh][wn * 32 + li];
+                        xb[(b8 + 1) & 1][u] = sm.x[2 * (8 * (b8 + 1) + u) + lh][wk * 32 + li];
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[b8 & 1][u], xb[b8 & 1][u], acc, 0, 0, 0);
             }
-            *reinterpret_cast<float4*>(&sy[r][c]) = vy;
-            *reinterpret_cast<float4*>(&sx[r][c]) = vx;
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int s = 0; s < CW_ROWS / 2; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sy[2 * s + lh][wn * 32 + li], sx[2 * s + lh][wk * 32 + li], acc, 0, 0, 0);
+        __syncthreads();                               // every wave is done with the tile
+        if (more) stage();
     }
     float* out = dW + (int64_t)tap * d.Cout * d.Cin;
 #pragma unroll
@@ -225,10 +289,18 @@ extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_
                    "unsupported descriptor");
     const int64_t M = (int64_t)d->N * d->Do * d->Ho * d->Wo;
     GSDD_CHECK_ARG(M < (1ll << 31), "more than 2^31 rows");
-    const int slabs = 8;
+    GSDD_CHECK_ARG((int64_t)d->N * d->Di * d->Hi * d->Wi < (1ll << 31), "more than 2^31 input rows");
+    GSDD_CHECK_ARG(d->oD > 0 && d->oH > 0 && d->oW > 0 && (int64_t)d->N * d->oD * d->oH * d->oW < (1ll << 31), "bad output dims");
     const int ntiles = (d->Cout + 63) / 64, ctiles = (d->Cin + 63) / 64;
-    const dim3 grid((unsigned)((M + (int64_t)CW_ROWS * slabs - 1) / ((int64_t)CW_ROWS * slabs)), ntiles * ctiles, d->ntaps);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
+    // rows per block: enough blocks to fill the chip (>= ~2048), as few atomics per dW element as that allows
+    const int64_t nslabs = (M + CW_ROWS - 1) / CW_ROWS;
+    const int64_t per_x = (int64_t)ntiles * ctiles * d->ntaps;
+    int64_t gx = (2048 + per_x - 1) / per_x;
+    gx = gx < 1 ? 1 : (gx > nslabs ? nslabs : gx);
+    int slabs = (int)((nslabs + gx - 1) / gx);
+    slabs = slabs < 8 ? (nslabs < 8 ? (int)nslabs : 8) : (slabs > 64 ? 64 : slabs);
+    const dim3 grid((unsigned)((nslabs + slabs - 1) / slabs), ntiles * ctiles, d->ntaps);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), sizeof(CwSmem), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }
