@@ -116,7 +116,7 @@ def lib():
         L.gsdd_wgrad.argtypes = [_p, _i, _p, _i, _i64, _i, _i, _p, _p, _p]
         L.gsdd_colsum.argtypes = [_p, _i, _i64, _i, _p, _p]
         L.gsdd_batch_rowsum.argtypes = [_p, _i, _i, _i, _p, _p]
-        L.gsdd_d3pm_attention_train.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p]
+        L.gsdd_d3pm_attention_train.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _p]
         L.gsdd_d3pm_attention_bwd.argtypes = [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]
         L.gsdd_d3pm_embed_bwd.argtypes = [_p, _p, _i, _i, _i, _i, _p, _p, _p]
         L.gsdd_small_linear_bwd.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p]

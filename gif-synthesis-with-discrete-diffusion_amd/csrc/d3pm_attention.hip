@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
                                                                 const uint4* __restrict__ vp, int B, int L, int H,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out, float* __restrict__ lse) {
     __shared__ AttnSmem4 sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqb = (L + 255) / 256;
@@ -530,10 +530,12 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
             const float a1 = __shfl(a, rowbase + (li & 3) + 4);
             const float a2 = __shfl(a, rowbase + (li & 3) + 8);
             const float l = __shfl(a, rowbase + 12);
+            const float mrow = __shfl(mq[j], rowbase + 4 * lg + r);       // this row's exponent offset lives on lane (query li)
             const int qi = q0 + 16 * j + 4 * lg + r;
             if (li < 4 && qi < L) {
                 const float o = (a + a1 * 0.00048828125f + a2 * 2.384185791015625e-07f) / l;
                 out[((int64_t)b * L + qi) * (H * 4) + h * 4 + li] = o;
+                if (lse != nullptr && li == 0) lse[(int64_t)h * M + (int64_t)b * L + qi] = mrow + log2f(l);   // log2 domain
             }
         }
     }
@@ -591,11 +593,32 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
         uint4* vp = kp + rows * 2;
         hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
         GSDD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(d3pm_attention_v4_kernel, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out);
+        hipLaunchKernelGGL(d3pm_attention_v4_kernel, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);
     }
     GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+// Training forward on the same matrix-pipe kernel: also writes the log2-domain log-sum-exp the backward kernels consume.
+// Returns GSDD_OK and sets *done = 1 when the fast path applies (L % 32 == 0 and a workspace was given).
+int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
+                               void* workspace, int64_t workspace_bytes, void* stream, int* done) {
+    *done = 0;
+    if (L % 32 != 0 || workspace == nullptr) return GSDD_OK;
+    GSDD_CHECK_ARG(workspace_bytes >= gsdd_d3pm_attention_workspace_bytes(B, L, H), "workspace too small");
+    GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)B * L * H;
+    uint4* kp = reinterpret_cast<uint4*>(workspace);
+    uint4* vp = kp + rows * 2;
+    hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
+    GSDD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(d3pm_attention_v4_kernel, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
+                       out, lse);
+    GSDD_CHECK_LAUNCH();
+    *done = 1;
     return GSDD_OK;
 }
 

@@ -129,23 +129,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
 }
 
 // column sums: out[n] += sum_m Y[m][n]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ld, int64_t M, int N, float* out, int rows_per_block) {
-    const int n = blockIdx.y * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+// out[n] += sum_r Y[r][n].  256 threads = cpb columns x (256 / cpb) row groups; 256 rows per block, LDS reduction over the row
+// groups, one atomic per column and block.
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ld, int64_t M, int N, float* out, int cpb) {
+    __shared__ float red[256];
+    const int c = threadIdx.x % cpb, rg = threadIdx.x / cpb, nrg = 256 / cpb;
+    const int n = blockIdx.y * cpb + c;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += Y[r * ld + n];
-    atomicAdd(out + n, s);
+    if (n < N)
+        for (int64_t r = r0 + rg; r < r1; r += nrg) s += Y[r * ld + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        for (int g = 1; g < nrg; ++g) s += red[g * cpb + c];
+        atomicAdd(out + n, s);
+    }
+}
+static inline int colsum_cpb(int N) {
+    int cpb = 256;
+    while (cpb > 1 && cpb / 2 >= N) cpb /= 2;
+    return cpb;
 }
 
-// per-batch row sums: out[b][c] = sum_{l} Y[b*L + l][c]   (gradient of the broadcast cross-attention vector)
-__global__ __launch_bounds__(64) void batch_rowsum_kernel(const float* Y, int L, int C, float* out) {
-    const int b = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int l = 0; l < L; ++l) s += (double)Y[((int64_t)b * L + l) * C + c];
-    out[(int64_t)b * C + c] = (float)s;
+// per-batch row sums: out[b][c] = sum_{l} Y[b*L + l][c]   (gradient of the broadcast cross-attention vector); out is zeroed
+// by the caller, blocks of 256 rows accumulate with atomics
+__global__ __launch_bounds__(256) void batch_rowsum_kernel(const float* Y, int L, int C, float* out, int cpb) {
+    __shared__ float red[256];
+    const int c = threadIdx.x % cpb, rg = threadIdx.x / cpb, nrg = 256 / cpb;
+    const int b = blockIdx.z, n = blockIdx.y * cpb + c;
+    const int l0 = blockIdx.x * CS_ROWS;
+    const int l1 = l0 + CS_ROWS < L ? l0 + CS_ROWS : L;
+    float s = 0.f;
+    if (n < C)
+        for (int l = l0 + rg; l < l1; l += nrg) s += Y[((int64_t)b * L + l) * C + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && n < C) {
+        for (int g = 1; g < nrg; ++g) s += red[g * cpb + c];
+        atomicAdd(out + (int64_t)b * C + n, s);
+    }
 }
 
 // ------------------------------------------------------------------ attention, head dim 4, training versions (VALU)
@@ -394,9 +419,9 @@ extern "C" int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int
     hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, dW, slabs);
     GSDD_CHECK_LAUNCH();
     if (db != nullptr) {
-        const int rpb = 2048;
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rpb - 1) / rpb), (N + 255) / 256), dim3(256), 0,
-                           (hipStream_t)stream, dY, ldy, M, N, db, rpb);
+        const int cpb = colsum_cpb(N);
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + CS_ROWS - 1) / CS_ROWS), (N + cpb - 1) / cpb), dim3(256), 0,
+                           (hipStream_t)stream, dY, ldy, M, N, db, cpb);
         GSDD_CHECK_LAUNCH();
     }
     return GSDD_OK;
@@ -404,23 +429,32 @@ extern "C" int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int
 
 extern "C" int gsdd_colsum(const float* Y, int ld, int64_t M, int N, float* out, void* stream) {
     GSDD_CHECK_ARG(Y && out && M > 0 && N > 0, "bad args");
-    const int rpb = 2048;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rpb - 1) / rpb), (N + 255) / 256), dim3(256), 0, (hipStream_t)stream, Y,
-                       ld, M, N, out, rpb);
+    const int cpb = colsum_cpb(N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + CS_ROWS - 1) / CS_ROWS), (N + cpb - 1) / cpb), dim3(256), 0,
+                       (hipStream_t)stream, Y, ld, M, N, out, cpb);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }
 
 extern "C" int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out, void* stream) {
     GSDD_CHECK_ARG(Y && out && B > 0 && L > 0 && C > 0, "bad args");
-    hipLaunchKernelGGL(batch_rowsum_kernel, dim3(B, (C + 63) / 64), dim3(64), 0, (hipStream_t)stream, Y, L, C, out);
+    GSDD_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), (hipStream_t)stream));
+    const int cpb = colsum_cpb(C);
+    hipLaunchKernelGGL(batch_rowsum_kernel, dim3((L + CS_ROWS - 1) / CS_ROWS, (C + cpb - 1) / cpb, B), dim3(256), 0, (hipStream_t)stream,
+                       Y, L, C, out, cpb);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }
 
+int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
+                               void* workspace, int64_t workspace_bytes, void* stream, int* done);      // d3pm_attention.hip
+
 extern "C" int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
-                                         float* lse, void* stream) {
+                                         float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
     GSDD_CHECK_ARG(q && k && v && out && lse && B > 0 && L > 0 && H > 0, "bad args");
+    int done = 0;
+    const int rc = gsdd_attention_v4_with_lse(q, k, v, B, L, H, out, lse, workspace, workspace_bytes, stream, &done);
+    if (rc != GSDD_OK || done) return rc;
     hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((L + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, q, k, v, B, L, H,
                        out, lse);
     GSDD_CHECK_LAUNCH();

@@ -36,6 +36,7 @@ class D3PMTrainer:
         sv = {"xt": xt, "t": t, "cond": flat, "layers": []}
         x = torch.empty((M, D), **f)
         ops.d3pm_embed(xt, p["emb"], p["pos"], x)
+        aws = ops.d3pm_attention_workspace(B, L, H, dev) if L % 32 == 0 else None     # pre-split K/V images (matrix-pipe forward)
         for lay in p["layers"]:
             s = {"x_in": x}
             s["stats1"] = ops.row_stats(x, torch.empty((M, 2), **f))
@@ -43,7 +44,7 @@ class D3PMTrainer:
             s["hn"] = ops.linear(x, eye, torch.empty((M, D), **f), bias=zero_b, ln=ln1, rows_per_batch=L)
             s["qkv"] = ops.linear(s["hn"], lay["wqkv"], torch.empty((3 * H, M, 4), **f), bias=lay["bqkv"], out_mode=2)
             s["y"], s["lse"] = torch.empty((M, D), **f), torch.empty((H * M,), **f)
-            ops.d3pm_attention_train(s["qkv"][0:H], s["qkv"][H:2 * H], s["qkv"][2 * H:], B, L, H, s["y"], s["lse"])
+            ops.d3pm_attention_train(s["qkv"][0:H], s["qkv"][H:2 * H], s["qkv"][2 * H:], B, L, H, s["y"], s["lse"], ws=aws)
             s["v2"] = ops.small_linear(flat, lay["wv2"], lay["bv2"])
             cvec = ops.small_linear(s["v2"], lay["wproj2"], lay["bproj2"])
             s["x1"] = ops.linear(s["y"], lay["wproj"], torch.empty((M, D), **f), bias=lay["bproj"], bvec=cvec, rows_per_batch=L,

@@ -344,8 +344,9 @@ def batch_rowsum(Y, B, L, stream=None):
     return out
 
 
-def d3pm_attention_train(q, k, v, B, L, H, out, lse, stream=None):
-    check(lib().gsdd_d3pm_attention_train(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(lse), stream_ptr(stream)))
+def d3pm_attention_train(q, k, v, B, L, H, out, lse, ws=None, stream=None):
+    check(lib().gsdd_d3pm_attention_train(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(lse), ptr(ws),
+                                          0 if ws is None else ws.numel() * ws.element_size(), stream_ptr(stream)))
 
 
 def d3pm_attention_bwd(q, k, v, o, dO, lse, B, L, H, stream=None):

@@ -266,9 +266,10 @@ int gsdd_colsum(const float* Y, int ld, int64_t M, int N, float* out, void* stre
 /* out[b][c] = sum_l Y[b*L+l][c] */
 int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out, void* stream);
 /* head-dim-4 self-attention for training: forward that also returns the log2-domain log-sum-exp per (head,row), and the
- * backward (dq|dk|dv rows [M][3*H*4]); scratch: float[H*M]. */
+ * backward (dq|dk|dv rows [M][3*H*4]); scratch: float[H*M].  With a workspace of gsdd_d3pm_attention_workspace_bytes() and
+ * L % 32 == 0 the forward runs on the matrix-pipe kernel of gsdd_d3pm_attention; workspace may be NULL (VALU kernel). */
 int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
-                              void* stream);
+                              void* workspace, int64_t workspace_bytes, void* stream);
 int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
                             int B, int L, int H, float* dqkv, float* scratch, void* stream);
 /* demb[tok] += dx, dpos[l] += dx */
