@@ -77,6 +77,27 @@ __device__ __forceinline__ void gemm64(const float* w, int pitch, int k0, int li
         }
 }
 
+// Same contraction with the MFMA operands swapped: acc[nt][r] = out[row (r&3)+8(r>>2)+4h][feature 32nt + li] — the feature is
+// on the lane, so a store instruction writes 2 x 128 contiguous bytes (used where the result goes straight to HBM).
+__device__ __forceinline__ void gemm64_rows(const float* w, int pitch, int li, int h, const float (&act)[32], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 a0 = *reinterpret_cast<const float4*>(w + (int64_t)li * pitch + 32 * t + 8 * g + 4 * h);
+            float4 a1 = *reinterpret_cast<const float4*>(w + (int64_t)(32 + li) * pitch + 32 * t + 8 * g + 4 * h);
+            const int r = 16 * t + 4 * g;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 0], a0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 0], a1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 1], a0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 1], a1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 2], a0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 2], a1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 3], a0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r + 3], a1.w, acc[1], 0, 0, 0);
+        }
+}
+
 __device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
@@ -252,72 +273,120 @@ __global__ __launch_bounds__(512, 1) void d3pm_logits_kernel(const LogitsArgs a)
     const int nch = (a.K + LCH - 1) / LCH;
     const int64_t nblocks = (a.M + 255) / 256;
 
-    float4 stage[8];
-    auto load_w = [&](int c) {
+    // Weight rows of the next chunk are staged a quarter per sub-chunk (8 registers): loaded before the sub-chunk's MFMAs, written
+    // to the other LDS buffer after them.  The loads are branch-free (rows past K read row K-1; the classes they produce are never
+    // stored) so that nothing waits on them, or on the logits stores still in flight, at the point of issue.
+    float4 stage[2];
+    auto load_w = [&](int c, int quarter) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 512 * i;               // 4096 float4 per chunk
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * (2 * quarter + i);  // 4096 float4 per chunk
             const int n = c * LCH + (idx >> 4), col = (idx & 15) * 4;
-            stage[i] = n < a.K ? *reinterpret_cast<const float4*>(a.w + (int64_t)n * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            stage[i] = *reinterpret_cast<const float4*>(a.w + (int64_t)(n < a.K ? n : a.K - 1) * D + col);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, int quarter) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 512 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * (2 * quarter + i);
             *reinterpret_cast<float4*>(&lds[(buf * LCH + (idx >> 4)) * W1P + (idx & 15) * 4]) = stage[i];
         }
     };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const int64_t m = blk * 256 + wave * 32 + li;
-        const bool valid = m < a.M;
-        const int64_t mc = valid ? m : a.M - 1;
-        float xr[32], act[32];
-        load_frag(a.x + mc * D, h, xr);
-        float mean, rstd;
-        row_norm(xr, mean, rstd);
+        const int64_t mc = m < a.M ? m : a.M - 1;
+        float act[32];
+        {
+            float xr[32];
+            load_frag(a.x + mc * D, h, xr);
+            float mean, rstd;
+            row_norm(xr, mean, rstd);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 gm = *reinterpret_cast<const float4*>(a.g + f);
-                const float4 bt = *reinterpret_cast<const float4*>(a.b + f);
-                const int r = 16 * t + 4 * g;
-                act[r + 0] = (xr[r + 0] - mean) * rstd * gm.x + bt.x;
-                act[r + 1] = (xr[r + 1] - mean) * rstd * gm.y + bt.y;
-                act[r + 2] = (xr[r + 2] - mean) * rstd * gm.z + bt.z;
-                act[r + 3] = (xr[r + 3] - mean) * rstd * gm.w + bt.w;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const int f = 32 * t + 8 * g + 4 * h;
+                    const float4 gm = *reinterpret_cast<const float4*>(a.g + f);
+                    const float4 bt = *reinterpret_cast<const float4*>(a.b + f);
+                    const int r = 16 * t + 4 * g;
+                    act[r + 0] = (xr[r + 0] - mean) * rstd * gm.x + bt.x;
+                    act[r + 1] = (xr[r + 1] - mean) * rstd * gm.y + bt.y;
+                    act[r + 2] = (xr[r + 2] - mean) * rstd * gm.z + bt.z;
+                    act[r + 3] = (xr[r + 3] - mean) * rstd * gm.w + bt.w;
+                }
+        }
         __syncthreads();                 // previous block's readers are done with both buffers
-        load_w(0);
-        store_w(0);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) { load_w(0, qd); store_w(0, qd); }
         __syncthreads();
+        const int64_t row_u = blk * 256 + wave_u * 32;                   // wave-uniform first row
+        const bool rows_full = row_u + 32 <= a.M;
+        const uint32_t vbyte = ((uint32_t)(4 * h) * (uint32_t)a.K + (uint32_t)li) * 4u;   // lane part of the store address (bytes < 2^32)
         for (int c = 0; c < nch; ++c) {
             const int buf = c & 1;
-            if (c + 1 < nch) load_w(c + 1);
+            const bool more = c + 1 < nch;
             const float* wl = lds + buf * LCH * W1P;
 #pragma unroll 1
             for (int sc = 0; sc < LCH / 64; ++sc) {
+                // (plain locals rather than the staging array: the array version ends up in scratch)
+                const int wi0 = tid + 512 * (2 * sc), wi1 = wi0 + 512;
+                const int wn0 = (c + 1) * LCH + (wi0 >> 4), wn1 = (c + 1) * LCH + (wi1 >> 4);
+                const int wr0 = more ? (wn0 < a.K ? wn0 : a.K - 1) : 0, wr1 = more ? (wn1 < a.K ? wn1 : a.K - 1) : 0;
+                const float4 st0 = *reinterpret_cast<const float4*>(a.w + (int64_t)wr0 * D + (wi0 & 15) * 4);
+                const float4 st1 = *reinterpret_cast<const float4*>(a.w + (int64_t)wr1 * D + (wi1 & 15) * 4);
+                __builtin_amdgcn_sched_barrier(0);         // keep the two loads above the MFMA block (the scheduler sinks them)
                 f32x16 acc[2];
                 zero2(acc);
-                gemm64<true>(wl + sc * 64 * W1P, W1P, 0, li, h, act, acc);
+                gemm64_rows(wl + sc * 64 * W1P, W1P, li, h, act, acc);
+                // lane = class n (li), register r = row (r&3) + 8(r>>2) + 4h of this wave's 32 rows.
+                // The stores read their data registers when they execute, so those registers must not be rewritten until the
+                // stores are acknowledged: the results are moved (bias added) into `o`, and the empty asm keeps `acc` alive past
+                // that point so that `o` cannot share registers with the accumulators the next sub-chunk's MFMAs overwrite.
+                const int nb = c * LCH + sc * 64;
+                float o[2][16];
+                // `o` still feeds the previous sub-chunk's stores; they were issued a whole MFMA block ago, so this wait is free
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                    const int n = nb + 32 * t + li;
+                    const float bb = a.bias[n < a.K ? n : a.K - 1];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = c * LCH + sc * 64 + 32 * t + 8 * g + 4 * h;
-                        if (valid && n < a.K) {
-                            const float4 bb = *reinterpret_cast<const float4*>(a.bias + n);
-                            const int r = 4 * g;
-                            *reinterpret_cast<float4*>(a.out + m * a.K + n) =
-                                make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
-                        }
+                    for (int r = 0; r < 16; ++r) o[t][r] = acc[t][r] + bb;
+                }
+                asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
+                // stores with a wave-uniform (SGPR) base and one 32-bit lane offset: the compiler's own addressing spends 64
+                // VGPRs on the 32 addresses and then spills
+                const char* tile = reinterpret_cast<const char*>(a.out + (row_u * a.K + nb));
+                if (rows_full && nb + 64 <= a.K) {
+                    // whole 32 x 64 tile in range (wave-uniform test): 32 unconditional stores, nothing waits between them
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const char* tr = tile + (int64_t)((r & 3) + 8 * (r >> 2)) * a.K * 4;
+                        asm volatile("global_store_dword %0, %1, %2\n\tglobal_store_dword %0, %3, %2 offset:128"
+                                     :: "v"(vbyte), "v"(o[0][r]), "s"(tr), "v"(o[1][r]) : "memory");
                     }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t mr = row_u + 4 * h + (r & 3) + 8 * (r >> 2);
+                            if (mr < a.M && nb + 32 * t + li < a.K)
+                                a.out[mr * a.K + nb + 32 * t + li] = o[t][r];
+                        }
+                }
+                // the quarter loaded before this sub-chunk's MFMAs goes to the other LDS buffer, which is free: every wave passed
+                // the barrier that ended the previous chunk
+                if (more) {
+                    *reinterpret_cast<float4*>(&lds[((buf ^ 1) * LCH + (wi0 >> 4)) * W1P + (wi0 & 15) * 4]) = st0;
+                    *reinterpret_cast<float4*>(&lds[((buf ^ 1) * LCH + (wi1 >> 4)) * W1P + (wi1 & 15) * 4]) = st1;
+                }
             }
-            if (c + 1 < nch) store_w(buf ^ 1);
-            __syncthreads();
+            // LDS-only barrier: __syncthreads() is also a fence and would wait for the logits stores above to be acknowledged
+            // (s_waitcnt vmcnt(0)) at every chunk
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
 }
