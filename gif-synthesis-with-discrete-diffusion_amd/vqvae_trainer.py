@@ -10,7 +10,7 @@ import torch.distributed as dist
 
 from . import ops
 from ._lib import GsddError
-from .vqvae import conv_taps, convT_phases
+from .vqvae import conv_taps, convT_phases, pack_conv0_weight
 
 
 def conv_dgrad_phases(kernel, stride, pad_front):
@@ -220,16 +220,42 @@ class VQVAETrainer:
 
         # ---- d total / d x_recon, total = w_recon * mse(x_recon, x)/0.06 + w_commit * 0.25 mse(z, emb)
         dxr = ops.lincomb(None, sv["x_recon"], x, w_recon * 2.0 / (0.06 * x.numel()))
-        dfine = ops.ncdhw_to_rows(dxr, 4, 0).view(-1, 4)                  # rows of the finest grid, channel padded 3 -> 4
-        pro_next = None
+        n_up = len(p["dec_convts"])
+        dfine = None
         # ---- decoder transposed convs, last to first
-        for i in reversed(range(len(p["dec_convts"]))):
+        for i in reversed(range(n_up)):
             ct, s = p["dec_convts"][i], sv["dec"][i]
             mod = vq.decoder.convts[i]
             stride = ct["stride"]
-            last = i == len(p["dec_convts"]) - 1
+            last = i == n_up - 1
             Bc, Tc, Hc, Wc = s["in_dims"]
             cin, cout = C_, ct["cout"]
+            if last and s["pro"] is None and cout <= 4:
+                # Cout = 3: the adjoint of the transposed conv is a strided conv over d(out), dIn[i] = sum_kk W[kk]^T dOut[i*s + kk - c]
+                # with c = (k-1) - s*pad_front.  On W-padded NDHWC4 rows the kw taps x 4 channels of one (kt, kh) are 16 contiguous
+                # floats, so both gradients run with K = 16 per tap (the same merge as the encoder's first conv) instead of
+                # 4-wide / 4-deep tiles padded to the 64 x 32 MFMA tile: data gradient = gsdd_gemm, weight gradient =
+                # gsdd_conv_wgrad with the operand roles swapped (its "input" is d(out), its "dY" the layer input).
+                k, pf = mod.kernel_size, mod.pad_front
+                cc = [kk - 1 - st * pp for kk, st, pp in zip(k, stride, pf)]
+                padw = max(cc[2], k[2] - stride[2] - cc[2], 0)
+                dYp = ops.ncdhw_to_rows(dxr, 4, padw)                          # (B, Tf, Hf, Wf + 2 padw, 4), zero pads
+                Tf, Hf, Wf = s["fine"]
+                fine_dims = (Bc, Tf, Hf, Wf + 2 * padw)
+                taps_m = ops.taps_tensor([(a - cc[0], b_ - cc[1], padw - cc[2]) for a in range(k[0]) for b_ in range(k[1])], dev)
+                db = torch.zeros((4,), **f)
+                ops.colsum(dYp.view(-1, 4), db)
+                g[f"decoder.convts.{i}.convt.bias"] = db[:cout].contiguous()
+                dwm = torch.zeros((k[0] * k[1], cin, k[2] * 4), **f)
+                ops.conv_wgrad(dYp, s["inp"], dwm, in_dims=fine_dims, out_grid=(Tc, Hc, Wc), stride=stride, taps=taps_m,
+                               ntaps=k[0] * k[1], cin=k[2] * 4, cout=cin, in_pitch=4)
+                g[f"decoder.convts.{i}.convt.weight"] = dwm.view(k[0], k[1], cin, k[2], 4).permute(2, 4, 0, 1, 3)[:, :cout].contiguous()
+                dact = ops.gemm(dYp, pack_conv0_weight(mod.convt.weight), torch.empty((Bc * Tc * Hc * Wc, cin), **f), in_dims=fine_dims,
+                                out_grid=(Tc, Hc, Wc), stride=stride, taps=taps_m, ntaps=k[0] * k[1], cin=k[2] * 4, in_pitch=4)
+                dfine = dact                                                  # (i > 0: a single convT has the BatchNorm prologue)
+                continue
+            if last:
+                dfine = ops.ncdhw_to_rows(dxr, 4, 0).view(-1, 4)              # rows of the finest grid, channel padded 3 -> 4
             cpad = 4 if last else cout
             dY = dfine if last else ops.relu_mask(dfine, s["out"])
             db = torch.zeros((cpad,), **f)

@@ -49,8 +49,12 @@ def case(G, golden, name):
         sd, a, cfg = golden("vqvae_ds244")
         rng = np.random.default_rng(3)
         return torch.from_numpy(a["x"]), sd, cfg, rng.permutation(32)
-    # random-initialised wider net: channel counts that are not multiples of the 64-wide tiles, stride-1 time axis in layer 2
-    cfg = dict(embedding_dim=12, n_codes=40, n_hiddens=48, n_res_layers=2, downsample=[2, 4, 4], sequence_length=4, resolution=16)
+    if name == "ds444":       # every transposed conv strides time too (the last one takes the merged-W gradient path with s_t = 2)
+        cfg = dict(embedding_dim=8, n_codes=16, n_hiddens=16, n_res_layers=1, downsample=[4, 4, 4], sequence_length=8, resolution=16)
+        xshape, nperm = (2, 3, 8, 16, 16), 2 * 2 * 4 * 4
+    else:                     # wider net: channel counts that are not multiples of the 64-wide tiles, stride-1 time axis in layer 2
+        cfg = dict(embedding_dim=12, n_codes=40, n_hiddens=48, n_res_layers=2, downsample=[2, 4, 4], sequence_length=4, resolution=16)
+        xshape, nperm = (3, 3, 4, 16, 16), 3 * 2 * 4 * 4
     torch.manual_seed(11)
     m = G.VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"], cfg["downsample"],
                 cfg["sequence_length"], cfg["resolution"])
@@ -63,8 +67,8 @@ def case(G, golden, name):
     sd["codebook.embeddings"] = 0.3 * torch.randn(cfg["n_codes"], cfg["embedding_dim"])
     sd["codebook.z_avg"] = sd["codebook.embeddings"].clone()
     sd["codebook.N"] = torch.ones(cfg["n_codes"])
-    x = torch.rand(3, 3, 4, 16, 16) - 0.5
-    return x, sd, cfg, np.random.default_rng(5).permutation(3 * 2 * 4 * 4)
+    x = torch.rand(*xshape) - 0.5
+    return x, sd, cfg, np.random.default_rng(5).permutation(nperm)
 
 
 def compare(got, want, tol=2e-3):
@@ -84,7 +88,7 @@ def compare(got, want, tol=2e-3):
     print("worst relative gradient error:", worst)
 
 
-@pytest.mark.parametrize("name", ["train_ds188", "ds244", "wide"])
+@pytest.mark.parametrize("name", ["train_ds188", "ds244", "wide", "ds444"])
 def test_vqvae_gradients_match_autograd_of_oracle(G, golden, name):
     from gsdd_amd.vqvae_trainer import VQVAETrainer
     x, sd, cfg, perm = case(G, golden, name)
