@@ -17,9 +17,13 @@ class MultistageTextMotionModel(BaseModel):
         self.autoencoder = instantiate(autoencoder, device=self.gpu_device, _recursive_=False) \
             if isinstance(autoencoder, dict) else autoencoder
         ckpt = (checkpoint_paths or {}).get("autoencoder") if isinstance(checkpoint_paths, dict) else checkpoint_paths
-        if ckpt and ckpt != "__None__":
-            state = torch.load(ckpt, map_location="cpu", weights_only=True)
-            self.autoencoder.load_state_dict(state.get("state_dict", state))
+        if ckpt and ckpt != "__None__":                 # load_checkpoints (multistage_text_motion_model.py:113-122)
+            from gsdd_amd.checkpoint import load_reference_checkpoint
+            load_reference_checkpoint(self.autoencoder, ckpt)
+        gen_ckpt = (checkpoint_paths or {}).get("generator") if isinstance(checkpoint_paths, dict) else None
+        if gen_ckpt and gen_ckpt != "__None__":
+            from gsdd_amd.checkpoint import load_reference_checkpoint
+            load_reference_checkpoint(self.generator, gen_ckpt)
         self.autoencoder.eval()
         self.lr_args = dict(lr_args)
         self.do_evaluation = do_evaluation

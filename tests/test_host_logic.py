@@ -106,3 +106,82 @@ def test_weight_packing_matches_conv_semantics():
                         if 0 <= t < 3 and 0 <= h < 6 and 0 <= ww < 6:
                             got[0, :, to * stride[0] + ph[0], ho * stride[1] + ph[1], wo * stride[2] + ph[2]] += wp[ti] @ xp[t, h, ww]
     torch.testing.assert_close(got, want, atol=1e-4, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- checkpoint interop
+def _tiny_vq():
+    import gsdd_amd
+    torch.manual_seed(3)
+    return gsdd_amd.VQVAE(None, 8, 32, 16, 1, [1, 8, 8], 4, 32)
+
+
+def test_checkpoint_lightning_prefix_roundtrip(tmp_path):
+    """Stage-1 Lightning checkpoints hold "generator.<key>"; the reference strips 10 characters
+    (multistage_text_motion_model.py:113-122).  Stage-2 checkpoints hold "autoencoder.<key>" next to the generator's."""
+    from gsdd_amd.checkpoint import lightning_state, load_reference_checkpoint
+    src, dst = _tiny_vq(), _tiny_vq()
+    with torch.no_grad():
+        for prm in src.parameters():
+            prm.add_(0.25)
+    assert dst.codebook._need_init
+    path = tmp_path / "stage1.ckpt"
+    torch.save(lightning_state(generator=src), path)
+    assert load_reference_checkpoint(dst, str(path)) == []
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert not dst.codebook._need_init
+    # stage-2 layout: the autoencoder sits under "autoencoder.", unrelated generator keys next to it
+    dst2 = _tiny_vq()
+    st = lightning_state(autoencoder=src)
+    st["state_dict"]["generator.diffusion_model.transformer.blocks.0.attn2.mask"] = torch.zeros(1, 1, 4, 4)
+    load_reference_checkpoint(dst2, st)
+    assert torch.equal(dst2.pre_vq_conv.conv.weight, src.pre_vq_conv.conv.weight)
+    # a bare state_dict loads too
+    dst3 = _tiny_vq()
+    load_reference_checkpoint(dst3, src.state_dict())
+    assert torch.equal(dst3.decoder.convts[0].convt.weight, src.decoder.convts[0].convt.weight)
+
+
+def test_checkpoint_mismatch_is_loud():
+    from gsdd_amd.checkpoint import load_reference_checkpoint
+    src, dst = _tiny_vq(), _tiny_vq()
+    sd = dict(src.state_dict())
+    sd.pop("encoder.conv_last.conv.bias")
+    with pytest.raises(KeyError):
+        load_reference_checkpoint(dst, sd)
+    sd = dict(src.state_dict())
+    sd["encoder.conv_last.conv.bias"] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        load_reference_checkpoint(dst, sd)
+
+
+def test_checkpoint_drops_only_documented_dead_keys():
+    import gsdd_amd
+    from gsdd_amd.checkpoint import load_reference_checkpoint
+    torch.manual_seed(0)
+
+    def build():
+        d = gsdd_amd.DalleMaskImageEmbedding(num_embed=16, spatial_size=[4, 4], embed_dim=64)
+        tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=16, block_activate="GELU2",
+                                            content_spatial_size=[4, 4], condition_dim=512, diffusion_step=10)
+        return gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=10, alpha_init_type="alpha1", guidance_scale=2,
+                                             content_seq_len=16)
+    src, dst = build(), build()
+    with torch.no_grad():
+        src.transformer.to_logits[1].bias.add_(1.0)
+    sd = {"generator.diffusion_model." + k: v for k, v in src.state_dict().items()}
+    sd["generator.diffusion_model.transformer.blocks.0.attn2.mask"] = torch.tril(torch.ones(16, 16)).view(1, 1, 16, 16)
+    sd["generator.diffusion_model.zero_vector"] = torch.zeros(1)
+    sd["generator.textencoder.clip_model.positional_embedding"] = torch.zeros(77, 512)
+
+    class Gen(torch.nn.Module):            # the generator glue owns `diffusion_model` (discrete_diffusion.py:11-12)
+        def __init__(self, dm):
+            super().__init__()
+            self.diffusion_model = dm
+    dropped = load_reference_checkpoint(Gen(dst), {"state_dict": sd})
+    assert sorted(dropped) == ["diffusion_model.transformer.blocks.0.attn2.mask", "diffusion_model.zero_vector",
+                               "textencoder.clip_model.positional_embedding"]
+    assert torch.equal(dst.transformer.to_logits[1].bias, src.transformer.to_logits[1].bias)
+    sd["generator.diffusion_model.transformer.blocks.0.attn1.bogus"] = torch.zeros(1)
+    with pytest.raises(KeyError):
+        load_reference_checkpoint(Gen(build()), {"state_dict": sd})
