@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgsdd.so")
 _lib = None
 
 EXPORTS = [
-    "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows",
+    "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows", "gsdd_preprocess_clip",
     "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
     "gsdd_codebook_ema", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
@@ -84,6 +84,7 @@ def lib():
         L.gsdd_gemm.argtypes = [C.POINTER(GemmDesc), _p]
         L.gsdd_row_stats.argtypes = [_p, _i64, _i, C.c_float, _p, _p]
         L.gsdd_ncdhw_to_rows.argtypes = [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]
+        L.gsdd_preprocess_clip.argtypes = [_p] + [_i] * 10 + [_p, _p]
         L.gsdd_axial_attention.argtypes = [_p, _i, _i, _i, _i, _i, _i, _p, _p]
         L.gsdd_nearest_code.argtypes = [_p, _i64, _i, _p, _i, _p, _p, _p]
         L.gsdd_bn_train_workspace_bytes.argtypes = [_i64, _i]

@@ -198,6 +198,43 @@ __global__ __launch_bounds__(256) void nearest_code_kernel(const float* z, int64
     }
 }
 
+// ------------------------------------------------------------------ clip preprocessing (ucf101_dataset.py:105-140)
+// uint8 THWC frames -> normalised (x/255 - mean)/std, bilinear resize of the shorter side to R (align_corners = false, PyTorch's
+// source-index rule with one rounding: src = max(fma(in/out, dst + 0.5, -0.5), 0)), centre crop, CTHW float32.  One thread per
+// output pixel, three channels each; stores are coalesced along x in each channel plane.
+__global__ __launch_bounds__(256) void preprocess_clip_kernel(const uint8_t* __restrict__ video, int N, int T, int H, int W, int t_out,
+                                                              int th, int tw, int h_start, int w_start, int R,
+                                                              float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)N * t_out * R * R;
+    if (i >= total) return;
+    const int x = (int)(i % R), y = (int)((i / R) % R);
+    const int t = (int)((i / ((int64_t)R * R)) % t_out), n = (int)(i / ((int64_t)R * R * t_out));
+    const float sy = (float)H / (float)th, sx = (float)W / (float)tw;
+    const float fy = fmaxf(fmaf(sy, (float)(y + h_start) + 0.5f, -0.5f), 0.f);
+    const float fx = fmaxf(fmaf(sx, (float)(x + w_start) + 0.5f, -0.5f), 0.f);
+    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    y0 = y0 < H - 1 ? y0 : H - 1;
+    x0 = x0 < W - 1 ? x0 : W - 1;
+    const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const uint8_t* frame = video + ((int64_t)n * T + t) * H * W * 3;
+    const uint8_t* p00 = frame + ((int64_t)y0 * W + x0) * 3;
+    const uint8_t* p01 = frame + ((int64_t)y0 * W + x1) * 3;
+    const uint8_t* p10 = frame + ((int64_t)y1 * W + x0) * 3;
+    const uint8_t* p11 = frame + ((int64_t)y1 * W + x1) * 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const int64_t plane = (int64_t)t_out * R * R;
+    float* o = out + (int64_t)n * 3 * plane + ((int64_t)t * R + y) * R + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a00 = ((float)p00[c] / 255.f - mean[c]) / stdv[c], a01 = ((float)p01[c] / 255.f - mean[c]) / stdv[c];
+        const float a10 = ((float)p10[c] / 255.f - mean[c]) / stdv[c], a11 = ((float)p11[c] / 255.f - mean[c]) / stdv[c];
+        const float top = (1.f - lx) * a00 + lx * a01, bot = (1.f - lx) * a10 + lx * a11;
+        o[c * plane] = (1.f - ly) * top + ly * bot;
+    }
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
@@ -260,6 +297,18 @@ extern "C" int gsdd_nearest_code(const float* z, int64_t M, int E, const float* 
     const size_t lds = (size_t)2 * NC_T * (E + 4) * sizeof(float);
     hipLaunchKernelGGL(nearest_code_kernel, dim3((unsigned)((M + NC_T - 1) / NC_T)), dim3(256), lds, (hipStream_t)stream, z,
                        M, E, cb, K, idx, zq);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_preprocess_clip(const uint8_t* video, int N, int T, int H, int W, int t_out, int th, int tw, int h_start,
+                                    int w_start, int R, float* out, void* stream) {
+    GSDD_CHECK_ARG(video && out, "null pointer");
+    GSDD_CHECK_ARG(N > 0 && T > 0 && H > 0 && W > 0 && R > 0 && t_out > 0 && t_out <= T, "bad sizes");
+    GSDD_CHECK_ARG(th >= R && tw >= R && h_start >= 0 && w_start >= 0 && h_start + R <= th && w_start + R <= tw, "crop outside the resized frame");
+    const int64_t total = (int64_t)N * t_out * R * R;
+    hipLaunchKernelGGL(preprocess_clip_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, video, N, T, H,
+                       W, t_out, th, tw, h_start, w_start, R, out);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

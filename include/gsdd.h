@@ -299,6 +299,13 @@ int gsdd_graph_end(void* stream, void** graph_exec_out);
 int gsdd_graph_launch(void* graph_exec, void* stream);
 int gsdd_graph_destroy(void* graph_exec);
 
+/* ------------------------------------------------------------------ clip preprocessing (next row)
+ * replaces `preprocess` (src/datamodules/datasets/ucf101_dataset.py:105-140): uint8 frames video[N][T][H][W][3] ->
+ * out[N][3][t_out][R][R] float32 = centre crop (h_start, w_start) of the bilinear resize (align_corners false) to th x tw of
+ * (x/255 - ImageNet mean)/std; the first t_out frames of each clip (temporal crop, :116-118). */
+int gsdd_preprocess_clip(const uint8_t* video, int N, int T, int H, int W, int t_out, int th, int tw, int h_start, int w_start,
+                         int R, float* out, void* stream);
+
 /* HIP-event timing on a given stream (bench.py measures the stream the kernels run on) */
 int gsdd_event_create(void** ev);
 int gsdd_event_record(void* ev, void* stream);

@@ -185,3 +185,19 @@ def test_checkpoint_drops_only_documented_dead_keys():
     sd["generator.diffusion_model.transformer.blocks.0.attn1.bogus"] = torch.zeros(1)
     with pytest.raises(KeyError):
         load_reference_checkpoint(Gen(build()), {"state_dict": sd})
+
+
+def test_clip_folder_dataset_enumerates_like_the_reference(tmp_path):
+    """classes = sorted parent directories, windows of `sequence_length` frames every 100 frames (ucf101_dataset.py:57-66)."""
+    import numpy as np
+    from src.datamodules.clip_folder_datamodule import ClipFolderDataset
+    for cls, n in (("Swing", 130), ("Archery", 20), ("Biking", 7)):
+        d = tmp_path / "train" / cls
+        d.mkdir(parents=True)
+        np.save(d / "v0.npy", np.zeros((n, 6, 8, 3), dtype=np.uint8))
+    ds = ClipFolderDataset(str(tmp_path), sequence_length=16, split="train", resolution=4)
+    assert ds.classes == ["Archery", "Biking", "Swing"] and ds.n_classes == 3
+    got = [(os.path.basename(os.path.dirname(f)), s) for f, s in ds.clips]
+    assert got == [("Archery", 0), ("Swing", 0), ("Swing", 100)]            # Biking is shorter than one window
+    item = ds[2]
+    assert item["label"] == 2 and item["text"] == "Swing" and tuple(item["frames"].shape) == (16, 6, 8, 3)

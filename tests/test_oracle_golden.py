@@ -109,3 +109,18 @@ def test_vqvae_train_forward_matches_reference():
             np.testing.assert_allclose(v.numpy(), after[k].numpy(), atol=2e-5, rtol=1e-4, err_msg=k)
         else:
             assert torch.equal(v, after[k]), k
+
+
+def test_preprocess_oracle_matches_reference_function():
+    """oracle/preprocess.py against outputs of the reference's `preprocess` (ucf101_dataset.py:105-140) on uint8 clips:
+    landscape / portrait / square, up- and down-scaling, odd sizes, with and without the temporal crop.  fp32 tolerance 1e-6
+    (the reference's vectorised bilinear kernel associates the four products differently: 1-3 ulp)."""
+    import os
+    from tests.conftest import GOLDEN
+    from oracle import preprocess as op
+    z = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    for i in range(5):
+        r, sl = (int(v) for v in z[f"cfg{i}"])
+        out = op.preprocess(z[f"in{i}"], r, None if sl < 0 else sl)
+        assert out.shape == z[f"out{i}"].shape
+        np.testing.assert_allclose(out, z[f"out{i}"], atol=1e-6, rtol=0)
