@@ -45,29 +45,28 @@ def build_models(args, device):
     return dm.to(device).eval(), vq.to(device).eval(), L
 
 
-def attention_roofline(dm, B2, L, H, device, iters=20):
-    """Dominant kernel (self-attention, head dim 4) timed with HIP events on its launch stream, on the q|k|v the
-    last reverse step of the timed region left in the workspace (in-situ operands: the kernel's clock is data
-    dependent, random Gaussian operands run ~15 % slower than the workload's own).  Algorithmic FLOPs = 16*L^2 per
-    (sample, head) (QK^T 2*4 + PV 2*4 per score).  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
-    committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), attention kernel + its K/V pre-split."""
-    M = B2 * L
-    ws = getattr(dm, "_last_ws", None)
-    if ws is not None and ws["qkv"].shape[1] == M:
-        q, aws = ws["qkv"], ws["attn"]
-    else:
-        q = torch.randn((3 * H, M, 4), device=device)
-        aws = gsdd_amd.ops.d3pm_attention_workspace(B2, L, H, device)
-    out = torch.empty((M, H * 4), device=device)
-    st = torch.cuda.current_stream()
-    for _ in range(3):
-        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, ws=aws, stream=st)
-    e0, e1 = gsdd_amd.ops.Event(), gsdd_amd.ops.Event()
-    e0.record(st)
-    for _ in range(iters):
-        gsdd_amd.ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, ws=aws, stream=st)
-    e1.record(st)
-    ms = e0.elapsed_ms(e1) / iters
+def attention_roofline(dm, B, L, H, device, K, reps=3):
+    """Dominant kernel (self-attention, head dim 4) timed live with HIP events on its launch stream, in situ: after the timed
+    region `reps` more denoiser passes run eagerly on the sampler's own stream and workspace, with an event pair around every
+    full-batch attention launch (the ABI call = K/V pre-split + the attention kernel), so the kernel sees the operands, cache
+    state and clocks of the real loop (a back-to-back loop of attention launches alone clocks ~6 % lower).  Algorithmic
+    FLOPs = 16*L^2 per (sample, head) (QK^T 2*4 + PV 2*4 per score).  `traffic` = HBM bytes per launch from the rocprofv3
+    PMC passes committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), both kernels."""
+    ws, (condv, Te, rep) = dm._last_ws, dm._last_run
+    B2 = rep * B
+    st = dm._stream
+    tok = torch.randint(0, K, (B, L), device=device)
+    tok[torch.rand((B, L), device=device) < 0.5] = K                  # half [MASK], like the middle of a chain
+    t2 = torch.full((B2,), dm.num_timesteps // 2, dtype=torch.int64, device=device)
+    events = []
+    with torch.cuda.stream(st):
+        dm.transformer.run(tok, condv, Te, t2, ws, rep=rep, stream=st)              # warm
+        ws["attn_events"] = events
+        for _ in range(reps):
+            dm.transformer.run(tok, condv, Te, t2, ws, rep=rep, stream=st)
+        ws.pop("attn_events")
+    st.synchronize()
+    ms = sum(e0.elapsed_ms(e1) for e0, e1 in events) / len(events)
     flops = 16.0 * L * L * H * B2
     tf = flops / (ms * 1e-3) / 1e12
     traffic = None
@@ -75,7 +74,7 @@ def attention_roofline(dm, B2, L, H, device, iters=20):
         traffic = (2 * 82019.4 + 42038.2 + 2 * 32784.4 + 131233.8) * 1024      # profiles/r1_pmc_traffic.csv
     return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel + d3pm_attn_prep_kernel", "achieved": round(tf, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+            "traffic": traffic, "ms_per_launch": round(ms, 4), "launches_timed": len(events), "flops_per_launch": flops}
 
 
 def cpu_baseline(args, dm, vq, L):
@@ -183,7 +182,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "hipgraph": not args.no_graph},
         }
-        line["roofline"] = attention_roofline(dm, 2 * B, L, 16, device)
+        line["roofline"] = attention_roofline(dm, B, L, 16, device, args.codes)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, dm, vq, L)
         print(json.dumps(line), flush=True)
