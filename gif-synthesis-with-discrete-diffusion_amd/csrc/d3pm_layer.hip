@@ -117,13 +117,44 @@ __device__ __forceinline__ void row_norm(const float (&v)[32], float& mean, floa
     rstd = 1.0f / sqrtf(q * (1.f / 64.f) + 1e-5f);
 }
 
+// 64 x 64 weight block streamed from global memory (L2-resident): all 16 fragments are requested before the first MFMA, so the
+// GEMM pays one L2 round trip instead of one per k-group.
+__device__ __forceinline__ void gemm64_global(const float* w, int li, int h, const float (&act)[32], f32x16 (&acc)[2]) {
+    float4 a0[8], a1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        a0[q] = *reinterpret_cast<const float4*>(w + (int64_t)li * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+        a1[q] = *reinterpret_cast<const float4*>(w + (int64_t)(32 + li) * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 16 * (q >> 2) + 4 * (q & 3);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, act[r + 0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, act[r + 0], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, act[r + 1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, act[r + 1], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, act[r + 2], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].z, act[r + 2], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].w, act[r + 3], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, act[r + 3], acc[1], 0, 0, 0);
+    }
+}
+
+// LDS map (floats): W1 [256][68] | W2 [64][260] | Wproj [64][68] | parameters (704) | per-wave scratch 8 x 192
+constexpr int LDS_W2 = HID * W1P, LDS_WP = LDS_W2 + D * W2P, LDS_PAR = LDS_WP + D * W1P;
+constexpr int PAR_BPROJ = 0, PAR_G2 = 64, PAR_B2LN = 128, PAR_B1 = 192, PAR_B2 = 448, PAR_BQKV = 512, PAR_N = 704;
+constexpr int LDS_SCR = LDS_PAR + PAR_N, LDS_LAYER_FLOATS = LDS_SCR + 8 * 192;
+
 template <bool HAS_QKV>
 __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sw1 = lds;                    // [256][68]
-    float* sw2 = lds + HID * W1P;        // [64][260]
+    float* sw2 = lds + LDS_W2;           // [64][260]
+    float* swp = lds + LDS_WP;           // [64][68]
+    float* par = lds + LDS_PAR;          // biases and LayerNorm affine: LDS latency instead of an L2 round trip at every use
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
+    float* scr = lds + LDS_SCR + wave * 192;   // this wave's per-batch vectors: cvec | 1+scale | shift of the group's batch element
 
     for (int i = tid; i < HID * (D / 4); i += 512) {             // W1 [256][64]
         const int n = i >> 4, c = (i & 15) * 4;
@@ -133,30 +164,60 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
         const int n = i >> 6, c = (i & 63) * 4;
         *reinterpret_cast<float4*>(&sw2[n * W2P + c]) = *reinterpret_cast<const float4*>(a.w2 + n * HID + c);
     }
+    for (int i = tid; i < D * (D / 4); i += 512) {               // Wproj [64][64]
+        const int n = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<float4*>(&swp[n * W1P + c]) = *reinterpret_cast<const float4*>(a.wproj + n * D + c);
+    }
+    for (int i = tid; i < PAR_N; i += 512) {
+        float v;
+        if (i < PAR_G2) v = a.bproj[i];
+        else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2];
+        else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN];
+        else if (i < PAR_B2) v = a.b1[i - PAR_B1];
+        else if (i < PAR_BQKV) v = a.b2[i - PAR_B2];
+        else v = HAS_QKV ? a.bqkv[i - PAR_BQKV] : 0.f;
+        par[i] = v;
+    }
     __syncthreads();
 
     const int64_t ngroups = (a.M + 31) / 32;
+    const bool batch_uniform = a.L % 32 == 0;              // every 32-row group lies inside one batch element
     for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
         const int64_t m = grp * 32 + li;
         const bool valid = m < a.M;
+        const bool full = grp * 32 + 32 <= a.M;            // wave-uniform: all 32 rows exist -> unconditional stores
         const int64_t mc = valid ? m : a.M - 1;
         const int b = (int)((uint32_t)mc / (uint32_t)a.L);
+
+        // per-batch vectors of this group -> the wave's LDS scratch (same wave writes and reads: program order suffices)
+        if (batch_uniform) {
+            const int bu = (int)((uint32_t)(grp * 32) / (uint32_t)a.L);
+            if (lane < 16) {
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)bu * D + 4 * lane);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = cv;
+            } else if (HAS_QKV && lane < 48) {
+                const float* tab = a.ada + a.t2[bu] * (2 * D);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = *reinterpret_cast<const float4*>(tab + 4 * (lane - 16));
+            }
+        }
 
         float act[32], x1[32];
         f32x16 acc[2];
         // ---- x1 = x + proj(y) + b_proj + cvec[b]
         load_frag(a.y + mc * D, h, act);
-        zero2(acc);
-        gemm64<false>(a.wproj, D, 0, li, h, act, acc);
         load_frag(a.x + mc * D, h, x1);
+        zero2(acc);
+        gemm64<true>(swp, W1P, 0, li, h, act, acc);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f = 32 * t + 8 * g + 4 * h;
-                const float4 bp = *reinterpret_cast<const float4*>(a.bproj + f);
-                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f);
+                const float4 bp = *reinterpret_cast<const float4*>(par + PAR_BPROJ + f);
+                float4 cv;
+                if (batch_uniform) cv = *reinterpret_cast<const float4*>(scr + f);
+                else cv = a.cvec != nullptr ? *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int r = 4 * g;
                 x1[16 * t + r + 0] += (acc[t][r + 0] + bp.x) + cv.x;
                 x1[16 * t + r + 1] += (acc[t][r + 1] + bp.y) + cv.y;
@@ -171,8 +232,8 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f = 32 * t + 8 * g + 4 * h;
-                const float4 gm = *reinterpret_cast<const float4*>(a.ln2_g + f);
-                const float4 bt = *reinterpret_cast<const float4*>(a.ln2_b + f);
+                const float4 gm = *reinterpret_cast<const float4*>(par + PAR_G2 + f);
+                const float4 bt = *reinterpret_cast<const float4*>(par + PAR_B2LN + f);
                 const int r = 16 * t + 4 * g;
                 act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
                 act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
@@ -191,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 bb = *reinterpret_cast<const float4*>(a.b1 + 64 * c + 32 * t + 8 * g + 4 * h);
+                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 8 * g + 4 * h);
                     const int r = 4 * g;
                     u[16 * t + r + 0] = gelu2(acc[t][r + 0] + bb.x);
                     u[16 * t + r + 1] = gelu2(acc[t][r + 1] + bb.y);
@@ -206,16 +267,24 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int f = 32 * t + 8 * g + 4 * h;
-                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + f);
+                const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B2 + f);
                 const int r = 4 * g;
-                float4 o;
-                o.x = x1[16 * t + r + 0] + (acc3[t][r + 0] + bb.x);
-                o.y = x1[16 * t + r + 1] + (acc3[t][r + 1] + bb.y);
-                o.z = x1[16 * t + r + 2] + (acc3[t][r + 2] + bb.z);
-                o.w = x1[16 * t + r + 3] + (acc3[t][r + 3] + bb.w);
-                x1[16 * t + r + 0] = o.x; x1[16 * t + r + 1] = o.y; x1[16 * t + r + 2] = o.z; x1[16 * t + r + 3] = o.w;
-                if (valid) *reinterpret_cast<float4*>(a.x + m * D + f) = o;
+                x1[16 * t + r + 0] += acc3[t][r + 0] + bb.x;
+                x1[16 * t + r + 1] += acc3[t][r + 1] + bb.y;
+                x1[16 * t + r + 2] += acc3[t][r + 2] + bb.z;
+                x1[16 * t + r + 3] += acc3[t][r + 3] + bb.w;
             }
+        if (full) {                                        // (a store under a lane mask makes the compiler wait for the previous one)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        } else if (valid) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        }
         if (HAS_QKV) {
             // ---- next block: AdaLN(x2, t) then q|k|v
             row_norm(x1, mean, rstd);
@@ -225,8 +294,14 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f = 32 * t + 8 * g + 4 * h;
-                    const float4 gm = *reinterpret_cast<const float4*>(tab + f);
-                    const float4 bt = *reinterpret_cast<const float4*>(tab + D + f);
+                    float4 gm, bt;
+                    if (batch_uniform) {
+                        gm = *reinterpret_cast<const float4*>(scr + 64 + f);
+                        bt = *reinterpret_cast<const float4*>(scr + 128 + f);
+                    } else {
+                        gm = *reinterpret_cast<const float4*>(tab + f);
+                        bt = *reinterpret_cast<const float4*>(tab + D + f);
+                    }
                     const int r = 16 * t + 4 * g;
                     act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
                     act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
@@ -236,18 +311,28 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
 #pragma unroll 1
             for (int c = 0; c < 3; ++c) {
                 zero2(acc);
-                gemm64<false>(a.wqkv + (int64_t)c * 64 * D, D, 0, li, h, act, acc);
+                gemm64_global(a.wqkv + (int64_t)c * 64 * D, li, h, act, acc);
+                float4 o[8];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int q = 0; q < 8; ++q) {
+                    const int t = q >> 2, r = 4 * (q & 3);
+                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
+                    o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
+                }
+                // 4 consecutive outputs = one head's 4 dims: head-major q|k|v rows
+                if (full) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = 64 * c + 32 * t + 8 * g + 4 * h;      // 4 consecutive outputs = one head's 4 dims
-                        const float4 bb = *reinterpret_cast<const float4*>(a.bqkv + n);
-                        const int r = 4 * g;
-                        const float4 o = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z,
-                                                     acc[t][r + 3] + bb.w);
-                        if (valid) *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o;
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
                     }
+                } else if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                }
             }
         }
     }
@@ -408,7 +493,7 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     a.wproj = d->wproj; a.bproj = d->bproj; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b;
     a.w1 = d->w1; a.b1 = d->b1; a.w2 = d->w2; a.b2 = d->b2;
     a.ada = d->ada; a.t2 = d->t2; a.wqkv = d->wqkv; a.bqkv = d->bqkv; a.qkv = d->qkv;
-    const size_t lds = (size_t)(HID * W1P + D * W2P) * sizeof(float);
+    const size_t lds = (size_t)LDS_LAYER_FLOATS * sizeof(float);
     const int64_t ngroups = (d->M + 31) / 32;
     const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
     static bool attr_done = false;

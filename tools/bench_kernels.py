@@ -148,20 +148,21 @@ def main():
         report("nearest_code 32768 x 4096 x 128", ms, 2.0 * Ml * 4096 * 128)
     if "step" in which:
         Bs = B2 // 2
-        logits = torch.randn((M, K), device=dev)
-        tok = torch.randint(0, K + 1, (Bs, L), device=dev)
-        t = torch.full((B2,), 50, dtype=torch.int64, device=dev)
-        sid = torch.zeros(1, dtype=torch.int64, device=dev)
-        d = gsdd_amd.DalleMaskImageEmbedding(num_embed=K, spatial_size=[64, 64], embed_dim=64)
-        tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
-                                            content_spatial_size=[64, 64], diffusion_step=100)
-        dm = gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", guidance_scale=2,
-                                           content_seq_len=L).cuda()
-        Mh = Bs * L
-        ms = timeit(lambda: ops.d3pm_step(logits[:Mh], logits[Mh:], tok, tok, dm._sched(), t, sid, K=K, T=100, guidance=2.0, seed=1))
-        by = 2.0 * Mh * K * 4
-        print(f"d3pm_step B={Bs}: {ms:.3f} ms  {by / ms / 1e6:.0f} GB/s algorithmic")
-
+        for Ks in [int(v) for v in os.environ.get("GSDD_STEP_K", str(K)).split(",")]:
+            Mh = Bs * L
+            logits = torch.randn((2 * Mh, Ks), device=dev)
+            tok = torch.randint(0, Ks + 1, (Bs, L), device=dev)
+            t = torch.full((B2,), 50, dtype=torch.int64, device=dev)
+            sid = torch.zeros(1, dtype=torch.int64, device=dev)
+            d = gsdd_amd.DalleMaskImageEmbedding(num_embed=Ks, spatial_size=[64, 64], embed_dim=64)
+            tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                                content_spatial_size=[64, 64], diffusion_step=100)
+            dm = gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", guidance_scale=2,
+                                               content_seq_len=L).cuda()
+            ms = timeit(lambda: ops.d3pm_step(logits[:Mh], logits[Mh:], tok, tok, dm._sched(), t, sid, K=Ks, T=100, guidance=2.0, seed=1))
+            by = 2.0 * Mh * Ks * 4
+            print(f"d3pm_step B={Bs} K={Ks}: {ms:.3f} ms  {by / ms / 1e6:.0f} GB/s algorithmic  {ms * 1e6 / (Mh * Ks) * 1e3:.2f} ps/element")
+            del logits
 
 if __name__ == "__main__":
     main()
