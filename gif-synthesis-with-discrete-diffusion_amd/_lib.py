@@ -16,8 +16,8 @@ EXPORTS = [
     "gsdd_codebook_ema", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
     "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_gelu2", "gsdd_ln_bwd", "gsdd_wgrad",
-    "gsdd_batch_rowsum", "gsdd_colsum", "gsdd_d3pm_attention_train", "gsdd_d3pm_attention_bwd", "gsdd_d3pm_embed_bwd", "gsdd_small_linear_bwd",
-    "gsdd_adaln_bwd", "gsdd_adam", "gsdd_advance",
+    "gsdd_batch_rowsum", "gsdd_colsum", "gsdd_d3pm_attention_train", "gsdd_d3pm_attention_bwd", "gsdd_d3pm_attention_bwd_workspace_bytes", "gsdd_d3pm_embed_bwd", "gsdd_small_linear_bwd",
+    "gsdd_adaln_bwd", "gsdd_adam", "gsdd_adam_multi", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
     "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
 ]
@@ -118,11 +118,14 @@ def lib():
         L.gsdd_colsum.argtypes = [_p, _i, _i64, _i, _p, _p]
         L.gsdd_batch_rowsum.argtypes = [_p, _i, _i, _i, _p, _p]
         L.gsdd_d3pm_attention_train.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _p]
-        L.gsdd_d3pm_attention_bwd.argtypes = [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]
+        L.gsdd_d3pm_attention_bwd.argtypes = [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _p]
+        L.gsdd_d3pm_attention_bwd_workspace_bytes.argtypes = [_i, _i, _i]
+        L.gsdd_d3pm_attention_bwd_workspace_bytes.restype = _i64
         L.gsdd_d3pm_embed_bwd.argtypes = [_p, _p, _i, _i, _i, _i, _p, _p, _p]
         L.gsdd_small_linear_bwd.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p]
         L.gsdd_adaln_bwd.argtypes = [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p]
         L.gsdd_adam.argtypes = [_p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]
+        L.gsdd_adam_multi.argtypes = [_p, _i, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]
         L.gsdd_advance.argtypes = [_p, _i, _i64, _p, _i64, _p]
         L.gsdd_philox_uniform.argtypes = [C.c_uint64, _i64, _i64, _i64, _i, _p, _p]
         L.gsdd_graph_begin.argtypes = [_p]

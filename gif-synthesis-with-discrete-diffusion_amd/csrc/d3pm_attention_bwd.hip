@@ -1,0 +1,463 @@
+// Backward of the head-dim-4 self-attention on the bf16 matrix pipe (training step of the D3PM denoiser).
+//
+// Same formulation as the forward kernel (d3pm_attention.hip): scores are recomputed tile by tile from error-free bf16
+// splits and never leave registers.  With s = c q.k - lse (log2 domain, lse from the forward), p = 2^s, dp = dO.v,
+// delta = dO.O:   dS = p (dp - delta),  dQ = 1/2 dS K,  dK = 1/2 dS^T Q,  dV = P^T dO.
+//   * both K=4 contractions (q.k and dO.v) are ONE v_mfma_f32_16x16x32_bf16 each: the six significant cross products of the
+//     3-way splits along K = 32, plus three slots carrying 1 * (-lse) resp. 1 * (-delta), so the tile comes out as s and
+//     dp - delta directly;
+//   * P and dS (f32 in registers) are split hi + lo in bf16 (16 significant bits) and multiplied with the 3-way bf16 splits of
+//     dO / K / Q on the matrix pipe (products exact in the f32 accumulator), like P.V in the forward.
+// Two kernels: dQ (a wave owns 64 queries, keys stream through LDS) and dK/dV (a wave owns 64 keys, queries stream).
+// All operand images are pre-split once per call by attn_bwd_prep_kernel (256 B per (row, head)).
+//
+// Reference semantics: autograd of FullAttention.forward (transformer_utils.py:46-62).
+#include "common.hpp"
+
+namespace gsdd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BKC = 256;           // rows (keys or queries) per LDS chunk
+
+__device__ __forceinline__ uint32_t bw_bf16_rn(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bw_split3(float x, uint32_t& a, uint32_t& b, uint32_t& c) {
+    a = bw_bf16_rn(x);
+    const float r = x - __uint_as_float(a << 16);
+    b = bw_bf16_rn(r);
+    const float r2 = r - __uint_as_float(b << 16);
+    c = bw_bf16_rn(r2);
+}
+__device__ __forceinline__ uint4 bw_pack8(const uint32_t (&lo)[4], const uint32_t (&hi)[4]) {
+    return make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+}
+__device__ __forceinline__ bf16x8 bw_frag(uint4 u) {
+    union { uint4 u; bf16x8 v; } c;
+    c.u = u;
+    return c.v;
+}
+// x as three bf16 pieces in contraction slots 24..26 (lane group 3's fragment); the facing fragment holds ones there
+__device__ __forceinline__ uint4 bw_slot_frag(float x) {
+    uint32_t a, b, c;
+    bw_split3(x, a, b, c);
+    return make_uint4(a | (b << 16), c, 0u, 0u);
+}
+__device__ __forceinline__ uint4 bw_ones_frag() { return make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u); }
+
+// "row" operand of a score MFMA (the side that comes from LDS): pieces A = [x1|x2] (faces [y1|y1] and [y2|y2]) and
+// B = [x3|x1] (faces [y1|y3]).  "col" operand (the side a wave keeps in registers), per lane group: [y1|y1] [y2|y2] [y1|y3] extra
+__device__ __forceinline__ void bw_row_pieces(const float (&x)[4], uint4& pa, uint4& pb) {
+    uint32_t x1[4], x2[4], x3[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) bw_split3(x[d], x1[d], x2[d], x3[d]);
+    pa = bw_pack8(x1, x2);
+    pb = bw_pack8(x3, x1);
+}
+__device__ __forceinline__ uint4 bw_col_frag(const float (&y)[4], int lg, uint4 extra) {
+    uint32_t y1[4], y2[4], y3[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) bw_split3(y[d], y1[d], y2[d], y3[d]);
+    const uint4 f0 = bw_pack8(y1, y1), f1 = bw_pack8(y2, y2), f2 = bw_pack8(y1, y3);
+    return lg == 0 ? f0 : (lg == 1 ? f1 : (lg == 2 ? f2 : extra));
+}
+// accumulate-side image ("V format"): per 32-row pair-tile [row group g][col j] -> 8 bf16 (tile0 rows 4g+r, tile1 rows 4g+r),
+// cols = [x1 | x2 | x3 | 0]
+__device__ __forceinline__ void bw_store_vformat(const float (&x)[4], int64_t row, uint4* img) {
+    uint16_t col[16];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t a, b, c;
+        bw_split3(x[d], a, b, c);
+        col[d] = (uint16_t)a; col[4 + d] = (uint16_t)b; col[8 + d] = (uint16_t)c; col[12 + d] = 0;
+    }
+    const int64_t pair = row >> 5;
+    const int kk = (int)(row & 31), th = kk >> 4, kt = kk & 15, g = kt >> 2, r = kt & 3;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(img + (pair * 4 + g) * 16) + 4 * th + r;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * 8] = col[j];
+}
+
+// Split 8 f32 values into packed bf16 hi / lo fragments: hi = bf16(x) (RNE), lo = bf16(x - hi).  One asm block ending in
+// s_nop 1 (hipcc does not pad the VALU-write -> MFMA-read hazard for registers written inside inline asm).
+__device__ __forceinline__ void bw_split8(const float (&x)[8], uint4& hi, uint4& lo) {
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_cvt_pk_bf16_f32 %0, %16, %17\n\t"
+        "v_cvt_pk_bf16_f32 %1, %18, %19\n\t"
+        "v_cvt_pk_bf16_f32 %2, %20, %21\n\t"
+        "v_cvt_pk_bf16_f32 %3, %22, %23\n\t"
+        "v_lshlrev_b32 %8, 16, %0\n\t"
+        "v_and_b32 %9, 0xffff0000, %0\n\t"
+        "v_lshlrev_b32 %10, 16, %1\n\t"
+        "v_and_b32 %11, 0xffff0000, %1\n\t"
+        "v_lshlrev_b32 %12, 16, %2\n\t"
+        "v_and_b32 %13, 0xffff0000, %2\n\t"
+        "v_lshlrev_b32 %14, 16, %3\n\t"
+        "v_and_b32 %15, 0xffff0000, %3\n\t"
+        "v_sub_f32 %8, %16, %8\n\t"
+        "v_sub_f32 %9, %17, %9\n\t"
+        "v_sub_f32 %10, %18, %10\n\t"
+        "v_sub_f32 %11, %19, %11\n\t"
+        "v_sub_f32 %12, %20, %12\n\t"
+        "v_sub_f32 %13, %21, %13\n\t"
+        "v_sub_f32 %14, %22, %14\n\t"
+        "v_sub_f32 %15, %23, %15\n\t"
+        "v_cvt_pk_bf16_f32 %4, %8, %9\n\t"
+        "v_cvt_pk_bf16_f32 %5, %10, %11\n\t"
+        "v_cvt_pk_bf16_f32 %6, %12, %13\n\t"
+        "v_cvt_pk_bf16_f32 %7, %14, %15\n\t"
+        "s_nop 1"
+        : "=&v"(hi.x), "=&v"(hi.y), "=&v"(hi.z), "=&v"(hi.w), "=&v"(lo.x), "=&v"(lo.y), "=&v"(lo.z), "=&v"(lo.w),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+}
+
+struct BwdImages {                 // all indexed by the head-major row h*M + b*L + i
+    uint4* kp;                     // [rows][2]  score-row image of K (slots swapped for (row&15) >= 8, as the forward's)
+    uint4* vk;                     // [rows][2]  score-row image of V
+    uint4* kv;                     // [rows/32][4][16] accumulate image of K
+    uint4* qp;                     // [rows][3]  score-row image of c*Q, third piece = -lse
+    uint4* gp;                     // [rows][3]  score-row image of dO, third piece = -delta
+    uint4* qv;                     // accumulate image of Q
+    uint4* gv;                     // accumulate image of dO
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ o,
+                                                            const float* __restrict__ dO, const float* __restrict__ lse, int64_t M,
+                                                            int H, BwdImages im) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;      // h*M + m
+    if (row >= M * H) return;
+    const int h = (int)(row / M);
+    const int64_t m = row - (int64_t)h * M;
+    const float4 rq = *reinterpret_cast<const float4*>(q + row * 4);
+    const float4 rk = *reinterpret_cast<const float4*>(k + row * 4);
+    const float4 rv = *reinterpret_cast<const float4*>(v + row * 4);
+    const float4 rg = *reinterpret_cast<const float4*>(dO + m * (H * 4) + h * 4);
+    const float4 ro = *reinterpret_cast<const float4*>(o + m * (H * 4) + h * 4);
+    const float delta = (rg.x * ro.x + rg.y * ro.y) + (rg.z * ro.z + rg.w * ro.w);
+    const float c = 0.5f * 1.4426950408889634f;
+    const float qs[4] = {rq.x * c, rq.y * c, rq.z * c, rq.w * c}, qr[4] = {rq.x, rq.y, rq.z, rq.w};
+    const float ks[4] = {rk.x, rk.y, rk.z, rk.w}, vs[4] = {rv.x, rv.y, rv.z, rv.w}, gs[4] = {rg.x, rg.y, rg.z, rg.w};
+    const int sw = (int)((row >> 3) & 1);
+    uint4 pa, pb;
+    bw_row_pieces(ks, pa, pb);
+    im.kp[row * 2 + sw] = pa; im.kp[row * 2 + (sw ^ 1)] = pb;
+    bw_row_pieces(vs, pa, pb);
+    im.vk[row * 2 + sw] = pa; im.vk[row * 2 + (sw ^ 1)] = pb;
+    bw_row_pieces(qs, pa, pb);
+    im.qp[row * 3 + 0] = pa; im.qp[row * 3 + 1] = pb; im.qp[row * 3 + 2] = bw_slot_frag(-lse[row]);
+    bw_row_pieces(gs, pa, pb);
+    im.gp[row * 3 + 0] = pa; im.gp[row * 3 + 1] = pb; im.gp[row * 3 + 2] = bw_slot_frag(-delta);
+    bw_store_vformat(ks, row, im.kv);
+    bw_store_vformat(qr, row, im.qv);
+    bw_store_vformat(gs, row, im.gv);
+}
+
+__device__ __forceinline__ unsigned bw_xcd_remap(unsigned wg, unsigned nwg) {
+    const unsigned q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+}
+
+// ------------------------------------------------------------------ dQ: a wave owns 64 queries, keys stream through LDS
+struct DqSmem {
+    uint4 k[2][BKC][2];
+    uint4 v[2][BKC][2];
+    uint4 kv[2][BKC / 32][4][16];
+    uint4 ones[16];
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ q, const float* __restrict__ o,
+                                                               const float* __restrict__ dO, const float* __restrict__ lse,
+                                                               BwdImages im, int B, int L, int H, float* __restrict__ dqkv) {
+    __shared__ DqSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqb = (L + 255) / 256;
+    const unsigned wg = bw_xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = wg % nqb;
+    const int h = (wg / nqb) % H, b = wg / (nqb * H);
+    const int64_t M = (int64_t)B * L;
+    const int64_t hrow0 = (int64_t)h * M + (int64_t)b * L;            // first head-major row of this (b,h)
+    const int li = lane & 15, lg = lane >> 4;
+    const int q0 = qblk * 256 + wave * 64;
+
+    if (tid < 16) sm.ones[tid] = (tid == 0 || tid == 1) ? bw_ones_frag() : make_uint4(0u, 0u, 0u, 0u);
+
+    // register operands of this wave's queries: c*q with -lse, dO with -delta (delta = dO . O)
+    const float c = 0.5f * 1.4426950408889634f;
+    uint4 qfrag[4], gfrag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int qi = q0 + 16 * j + li;
+        qi = qi < L ? qi : L - 1;
+        const float4 qv = *reinterpret_cast<const float4*>(q + (hrow0 + qi) * 4);
+        const int64_t row = (int64_t)b * L + qi;
+        const float4 g = *reinterpret_cast<const float4*>(dO + row * (H * 4) + h * 4);
+        const float4 ov = *reinterpret_cast<const float4*>(o + row * (H * 4) + h * 4);
+        const float delta = (g.x * ov.x + g.y * ov.y) + (g.z * ov.z + g.w * ov.w);
+        const float qs[4] = {qv.x * c, qv.y * c, qv.z * c, qv.w * c}, gs[4] = {g.x, g.y, g.z, g.w};
+        qfrag[j] = bw_col_frag(qs, lg, bw_slot_frag(-lse[hrow0 + qi]));
+        gfrag[j] = bw_col_frag(gs, lg, bw_slot_frag(-delta));
+    }
+
+    const int nchunks = (L + BKC - 1) / BKC;
+    uint4 r0, r1, r2, r3, r4, r5;
+    auto load_chunk = [&](int ch) {
+        const int keys = min(BKC, L - ch * BKC);                      // multiple of 32
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const uint4* ks = im.kp + (hrow0 + (int64_t)ch * BKC) * 2;
+        const uint4* vs = im.vk + (hrow0 + (int64_t)ch * BKC) * 2;
+        const uint4* kvs = im.kv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
+        const bool a0 = tid < keys * 2, a1 = tid + 256 < keys * 2;
+        r0 = a0 ? ks[tid] : z; r1 = a1 ? ks[tid + 256] : z;
+        r2 = a0 ? vs[tid] : z; r3 = a1 ? vs[tid + 256] : z;
+        r4 = a0 ? kvs[tid] : z; r5 = a1 ? kvs[tid + 256] : z;
+    };
+    auto store_chunk = [&](int buf) {
+        uint4* kd = &sm.k[buf][0][0];
+        uint4* vd = &sm.v[buf][0][0];
+        uint4* kvd = &sm.kv[buf][0][0][0];
+        kd[tid] = r0; kd[tid + 256] = r1;
+        vd[tid] = r2; vd[tid + 256] = r3;
+        kvd[tid] = r4; kvd[tid + 256] = r5;
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; acc[j][3] = 0.f; }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int slot = ((lg >> 1) ^ (li >> 3)) & 1;
+    const int rstep = (lg == 3) ? 0 : 32;                              // uint4 stride between consecutive 16-row tiles
+    const int rbuf = (lg == 3) ? 0 : BKC * 2;
+    const uint4* kbase0 = (lg == 3) ? &sm.ones[(li >= 4 && li < 12) ? 0 : 1] : &sm.k[0][li][slot];
+    const uint4* vbase0 = (lg == 3) ? &sm.ones[(li >= 4 && li < 12) ? 0 : 1] : &sm.v[0][li][slot];
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        const int npairs = min(BKC, L - ch * BKC) >> 5;
+        const uint4* kb = kbase0 + buf * rbuf;
+        const uint4* vb = vbase0 + buf * rbuf;
+        for (int u = 0; u < npairs; ++u) {
+            const bf16x8 kf0 = bw_frag(kb[(2 * u) * rstep]), kf1 = bw_frag(kb[(2 * u + 1) * rstep]);
+            const bf16x8 vf0 = bw_frag(vb[(2 * u) * rstep]), vf1 = bw_frag(vb[(2 * u + 1) * rstep]);
+            const bf16x8 kvb = bw_frag(sm.kv[buf][u][lg][li]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, bw_frag(qfrag[j]), zero, 0, 0, 0);
+                const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, bw_frag(qfrag[j]), zero, 0, 0, 0);
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, bw_frag(gfrag[j]), zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, bw_frag(gfrag[j]), zero, 0, 0, 0);
+                float ds[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ds[r] = __builtin_amdgcn_exp2f(s0[r]) * d0[r];
+                    ds[4 + r] = __builtin_amdgcn_exp2f(s1[r]) * d1[r];
+                }
+                uint4 hi, lo;
+                bw_split8(ds, hi, lo);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(hi), kvb, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(lo), kvb, acc[j], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[query 4lg+r][col li], cols = [k1 | k2 | k3] sums: dq_d = 1/2 (D[d] + D[4+d] + D[8+d])
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = acc[j][r];
+            const int rowbase = lane & 48;
+            const float a1 = __shfl(a, rowbase + (li & 3) + 4);
+            const float a2 = __shfl(a, rowbase + (li & 3) + 8);
+            const int qi = q0 + 16 * j + 4 * lg + r;
+            if (li < 4 && qi < L) dqkv[((int64_t)b * L + qi) * (3 * H * 4) + h * 4 + li] = 0.5f * ((a + a1) + a2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ dK, dV: a wave owns 64 keys, queries stream through LDS
+struct DkvSmem {
+    uint4 q[2][BKC][3];
+    uint4 g[2][BKC][3];
+    uint4 qv[2][BKC / 32][4][16];
+    uint4 gv[2][BKC / 32][4][16];
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                                BwdImages im, int B, int L, int H, float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char dkv_raw[];
+    DkvSmem& sm = *reinterpret_cast<DkvSmem*>(dkv_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkb = (L + 255) / 256;
+    const unsigned wg = bw_xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = wg % nkb;
+    const int h = (wg / nkb) % H, b = wg / (nkb * H);
+    const int64_t M = (int64_t)B * L;
+    const int64_t hrow0 = (int64_t)h * M + (int64_t)b * L;
+    const int li = lane & 15, lg = lane >> 4;
+    const int k0 = kblk * 256 + wave * 64;
+
+    // register operands of this wave's keys: [k1|k1] [k2|k2] [k1|k3] ones  and the same for v
+    uint4 kfrag[4], vfrag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ki = k0 + 16 * j + li;
+        ki = ki < L ? ki : L - 1;
+        const float4 kk = *reinterpret_cast<const float4*>(k + (hrow0 + ki) * 4);
+        const float4 vv = *reinterpret_cast<const float4*>(v + (hrow0 + ki) * 4);
+        const float ks[4] = {kk.x, kk.y, kk.z, kk.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
+        kfrag[j] = bw_col_frag(ks, lg, bw_ones_frag());
+        vfrag[j] = bw_col_frag(vs, lg, bw_ones_frag());
+    }
+
+    const int nchunks = (L + BKC - 1) / BKC;
+    uint4 r[10];
+    auto load_chunk = [&](int ch) {
+        const int rows = min(BKC, L - ch * BKC);                      // multiple of 32
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        const uint4* qs = im.qp + (hrow0 + (int64_t)ch * BKC) * 3;
+        const uint4* gs = im.gp + (hrow0 + (int64_t)ch * BKC) * 3;
+        const uint4* qvs = im.qv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
+        const uint4* gvs = im.gv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool ok = tid + 256 * i < rows * 3;
+            r[i] = ok ? qs[tid + 256 * i] : z;
+            r[3 + i] = ok ? gs[tid + 256 * i] : z;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = tid + 256 * i < rows * 2;
+            r[6 + i] = ok ? qvs[tid + 256 * i] : z;
+            r[8 + i] = ok ? gvs[tid + 256 * i] : z;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        uint4* qd = &sm.q[buf][0][0];
+        uint4* gd = &sm.g[buf][0][0];
+        uint4* qvd = &sm.qv[buf][0][0][0];
+        uint4* gvd = &sm.gv[buf][0][0][0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { qd[tid + 256 * i] = r[i]; gd[tid + 256 * i] = r[3 + i]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { qvd[tid + 256 * i] = r[6 + i]; gvd[tid + 256 * i] = r[8 + i]; }
+    };
+
+    f32x4 acck[4], accv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acck[j][e] = 0.f; accv[j][e] = 0.f; }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int piece = lg < 2 ? 0 : lg - 1;                            // lane group -> piece of the query row: A A B C
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        const int npairs = min(BKC, L - ch * BKC) >> 5;
+        for (int u = 0; u < npairs; ++u) {
+            const bf16x8 qa0 = bw_frag(sm.q[buf][32 * u + li][piece]), qa1 = bw_frag(sm.q[buf][32 * u + 16 + li][piece]);
+            const bf16x8 ga0 = bw_frag(sm.g[buf][32 * u + li][piece]), ga1 = bw_frag(sm.g[buf][32 * u + 16 + li][piece]);
+            const bf16x8 qvb = bw_frag(sm.qv[buf][u][lg][li]), gvb = bw_frag(sm.gv[buf][u][lg][li]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, bw_frag(kfrag[j]), zero, 0, 0, 0);
+                const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, bw_frag(kfrag[j]), zero, 0, 0, 0);
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, bw_frag(vfrag[j]), zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, bw_frag(vfrag[j]), zero, 0, 0, 0);
+                float p[8], ds[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = __builtin_amdgcn_exp2f(s0[e]); p[4 + e] = __builtin_amdgcn_exp2f(s1[e]);
+                    ds[e] = p[e] * d0[e]; ds[4 + e] = p[4 + e] * d1[e];
+                }
+                uint4 phi, plo, dhi, dlo;
+                bw_split8(p, phi, plo);
+                bw_split8(ds, dhi, dlo);
+                accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(phi), gvb, accv[j], 0, 0, 0);
+                accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(plo), gvb, accv[j], 0, 0, 0);
+                acck[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(dhi), qvb, acck[j], 0, 0, 0);
+                acck[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(dlo), qvb, acck[j], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[key 4lg+r][col li]: dk_d = 1/2 (D[d] + D[4+d] + D[8+d]) over [q1|q2|q3], dv_d likewise over [g1|g2|g3]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rowbase = lane & 48;
+            const float ak = acck[j][e], av = accv[j][e];
+            const float ak1 = __shfl(ak, rowbase + (li & 3) + 4), ak2 = __shfl(ak, rowbase + (li & 3) + 8);
+            const float av1 = __shfl(av, rowbase + (li & 3) + 4), av2 = __shfl(av, rowbase + (li & 3) + 8);
+            const int ki = k0 + 16 * j + 4 * lg + e;
+            if (li < 4 && ki < L) {
+                float* dst = dqkv + ((int64_t)b * L + ki) * (3 * H * 4);
+                dst[H * 4 + h * 4 + li] = 0.5f * ((ak + ak1) + ak2);
+                dst[2 * H * 4 + h * 4 + li] = (av + av1) + av2;
+            }
+        }
+    }
+}
+
+}  // namespace gsdd
+
+using namespace gsdd;
+
+extern "C" int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H) {
+    return (int64_t)B * L * H * 16 * 16;          // 16 uint4 per (row, head): kp 2, vk 2, kv 2, qp 3, gp 3, qv 2, gv 2
+}
+
+// Matrix-pipe backward; returns GSDD_OK with *done = 0 when the shape needs the VALU kernels (L % 32 != 0 or no workspace).
+int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse, int B,
+                            int L, int H, float* dqkv, void* workspace, int64_t workspace_bytes, void* stream, int* done) {
+    *done = 0;
+    if (L % 32 != 0 || workspace == nullptr) return GSDD_OK;
+    GSDD_CHECK_ARG(workspace_bytes >= gsdd_d3pm_attention_bwd_workspace_bytes(B, L, H), "workspace too small");
+    GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
+    const int64_t M = (int64_t)B * L, rows = M * H;
+    BwdImages im;
+    uint4* w = reinterpret_cast<uint4*>(workspace);
+    im.kp = w; w += rows * 2;
+    im.vk = w; w += rows * 2;
+    im.kv = w; w += rows * 2;
+    im.qp = w; w += rows * 3;
+    im.gp = w; w += rows * 3;
+    im.qv = w; w += rows * 2;
+    im.gv = w;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, q, k, v, o, dO, lse, M, H, im);
+    GSDD_CHECK_LAUNCH();
+    const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, q, o, dO, lse, im, B, L, H, dqkv);
+    GSDD_CHECK_LAUNCH();
+    static bool attr_done = false;
+    if (!attr_done) {
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sizeof(DkvSmem)));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), sizeof(DkvSmem), st, k, v, im, B, L, H, dqkv);
+    GSDD_CHECK_LAUNCH();
+    *done = 1;
+    return GSDD_OK;
+}

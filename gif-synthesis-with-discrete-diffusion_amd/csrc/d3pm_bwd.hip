@@ -3,6 +3,8 @@
 //   contraction over rows, column sums (bias gradients), head-dim-4 attention forward-with-LSE and its two backward
 //   kernels (dQ ; dK,dV), embedding scatter, tiny per-batch linears, Adam.
 // Reference semantics: autograd of transformer_utils.py:24-62,138-159,258-282,353-356 and dalle_mask_image_embedding.py:59-79.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace gsdd {
@@ -384,9 +386,39 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
     p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// Adam over many tensors in one launch: table[b] = {p, g, m, v, n} for block b (up to ADAM_CHUNK elements of one tensor)
+constexpr int ADAM_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adam_multi_kernel(const int64_t* __restrict__ table, float lr, float b1, float b2, float eps,
+                                                         float bc1, float bc2) {
+    const int64_t* e = table + (int64_t)blockIdx.x * 5;
+    float* p = reinterpret_cast<float*>(e[0]);
+    const float* g = reinterpret_cast<const float*>(e[1]);
+    float* m = reinterpret_cast<float*>(e[2]);
+    float* v = reinterpret_cast<float*>(e[3]);
+    const int n = (int)e[4];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
+
+extern "C" int gsdd_adam_multi(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, int step,
+                               void* stream) {
+    GSDD_CHECK_ARG(table != nullptr && n_blocks > 0 && step >= 1, "bad args");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, table, lr, beta1, beta2, eps,
+                       bc1, bc2);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
 
 extern "C" int gsdd_gelu2(const float* a, const float* du, float* out, int64_t n, int backward, void* stream) {
     GSDD_CHECK_ARG(a && out && n > 0 && n % 4 == 0 && (!backward || du), "bad args");
@@ -461,9 +493,21 @@ extern "C" int gsdd_d3pm_attention_train(const float* q, const float* k, const f
     return GSDD_OK;
 }
 
+int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse, int B,
+                            int L, int H, float* dqkv, void* workspace, int64_t workspace_bytes, void* stream,
+                            int* done);                                                      // d3pm_attention_bwd.hip
+
 extern "C" int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO,
-                                       const float* lse, int B, int L, int H, float* dqkv, float* scratch, void* stream) {
-    GSDD_CHECK_ARG(q && k && v && o && dO && lse && dqkv && scratch && B > 0 && L > 0 && H > 0, "bad args");
+                                       const float* lse, int B, int L, int H, float* dqkv, float* scratch, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+    GSDD_CHECK_ARG(q && k && v && o && dO && lse && dqkv && B > 0 && L > 0 && H > 0, "bad args");
+    static const bool force_valu = getenv("GSDD_ATTN_BWD_VALU") != nullptr;     // A/B switch
+    if (!force_valu) {
+        int done = 0;
+        const int rc = gsdd_attention_bwd_mfma(q, k, v, o, dO, lse, B, L, H, dqkv, workspace, workspace_bytes, stream, &done);
+        if (rc != GSDD_OK || done) return rc;
+    }
+    GSDD_CHECK_ARG(scratch != nullptr, "the VALU backward needs the float[H*M] scratch");
     const dim3 grid((L + 255) / 256, H, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, dO, lse, B, L, H, dqkv, scratch);
     GSDD_CHECK_LAUNCH();

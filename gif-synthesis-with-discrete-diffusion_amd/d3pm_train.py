@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from ._optim import GradArena, MultiAdam
 from ._lib import GsddError
 
 
@@ -90,9 +91,12 @@ class D3PMTrainer:
         dlogits = ops.d3pm_train_loss_bwd(sv["logits"], x0, xt, t, pt, sched, **kw)
 
         g = {}
+        if getattr(self, "_arena", None) is None:
+            self._arena = GradArena(dev)
+        self._arena.reset()                       # every gradient below is a zero-filled view of one buffer: one fill per step
 
         def z(name, like):
-            g[name] = torch.zeros_like(like)
+            g[name] = self._arena.zeros_like(like)
             return g[name]
 
         def tw(w):                              # transposed copy for the data-gradient GEMMs
@@ -104,6 +108,7 @@ class D3PMTrainer:
         dx = ops.ln_bwd(dhf, sv["x_out"], sv["statsf"], p["gf"], dgamma=z("to_logits.0.weight", p["gf"]),
                         dbeta=z("to_logits.0.bias", p["bf"]), gacc_stride=D)
         del dlogits
+        bws = ops.d3pm_attention_bwd_workspace(B, L, H, dx.device) if L % 32 == 0 else None     # operand images (matrix-pipe backward)
         for i in reversed(range(len(p["layers"]))):
             lay, s = p["layers"][i], sv["layers"][i]
             pre = f"blocks.{i}."
@@ -131,7 +136,7 @@ class D3PMTrainer:
             dy = ops.linear(dx1, tw(lay["wproj"]), torch.empty((B * L, D), **f))
             # ---- self-attention
             qkv = s["qkv"]
-            dqkv = ops.d3pm_attention_bwd(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], s["y"], dy, s["lse"], B, L, H)
+            dqkv = ops.d3pm_attention_bwd(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], s["y"], dy, s["lse"], B, L, H, ws=bws)
             wq = z(pre + "_wqkv", lay["wqkv"])
             bq = z(pre + "_bqkv", lay["bqkv"])
             ops.wgrad(dqkv, s["hn"], wq, bq)
@@ -149,10 +154,10 @@ class D3PMTrainer:
         # ---- embeddings
         ce = tr.content_emb
         Hs, Ws = ce.spatial_size
-        dpos = torch.zeros((Hs * Ws, D), **f)
+        dpos = self._arena.zeros((Hs * Ws, D))
         ops.d3pm_embed_bwd(dx, xt, z("content_emb.emb.weight", ce.emb.weight), dpos)
         g["content_emb.height_emb.weight"] = ops.batch_rowsum(dpos, Hs, Ws)
-        dw_ = torch.zeros((Ws * D,), **f)
+        dw_ = self._arena.zeros((Ws * D,))
         ops.colsum(dpos.view(Hs, Ws * D), dw_)
         g["content_emb.width_emb.weight"] = dw_.view(Ws, D)
         return fwd["loss"], g
@@ -174,9 +179,9 @@ class D3PMTrainer:
                 grads[n] = flat[off:off + k].view_as(grads[n])
                 off += k
         self.step_count += 1
-        for n, prm in params.items():
-            gr = grads[n].contiguous()
-            st = self.state.setdefault(n, (torch.zeros_like(prm), torch.zeros_like(prm)))
-            ops.adam(prm.data, gr, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        if getattr(self, "_adam", None) is None:
+            self._adam = MultiAdam(list(params.items()), self.lr, self.betas, self.eps)
+        self._adam.lr = self.lr
+        self._adam.step(grads)                  # all parameters in one launch
         tr._packed = None                       # parameters changed in place through raw pointers
         return loss

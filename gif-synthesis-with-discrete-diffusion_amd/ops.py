@@ -349,11 +349,16 @@ def d3pm_attention_train(q, k, v, B, L, H, out, lse, ws=None, stream=None):
                                           0 if ws is None else ws.numel() * ws.element_size(), stream_ptr(stream)))
 
 
-def d3pm_attention_bwd(q, k, v, o, dO, lse, B, L, H, stream=None):
+def d3pm_attention_bwd_workspace(B, L, H, device):
+    n = lib().gsdd_d3pm_attention_bwd_workspace_bytes(B, L, H)
+    return torch.empty((n // 4,), dtype=torch.float32, device=device)
+
+
+def d3pm_attention_bwd(q, k, v, o, dO, lse, B, L, H, ws=None, stream=None):
     dqkv = torch.empty((B * L, 3 * H * 4), dtype=torch.float32, device=q.device)
     scratch = torch.empty((H * B * L,), dtype=torch.float32, device=q.device)
-    check(lib().gsdd_d3pm_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), B, L, H, ptr(dqkv), ptr(scratch),
-                                        stream_ptr(stream)))
+    check(lib().gsdd_d3pm_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), B, L, H, ptr(dqkv), ptr(scratch), ptr(ws),
+                                        0 if ws is None else ws.numel() * ws.element_size(), stream_ptr(stream)))
     return dqkv
 
 

@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from ._optim import MultiAdam
 from ._lib import GsddError
 from .vqvae import conv_taps, convT_phases, pack_conv0_weight
 
@@ -360,9 +361,10 @@ class VQVAETrainer:
         losses, grads = self.loss_and_grads(x)
         grads = self.all_reduce_grads(grads)
         self.step_count += 1
-        for n, prm in self.vq.named_parameters():
-            st = self.state.setdefault(n, (torch.zeros_like(prm), torch.zeros_like(prm)))
-            ops.adam(prm.data, grads[n].contiguous(), st[0], st[1], self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        if getattr(self, "_adam", None) is None:
+            self._adam = MultiAdam(list(self.vq.named_parameters()), self.lr, self.betas, self.eps)
+        self._adam.lr = self.lr
+        self._adam.step(grads)                  # all parameters in one launch (gsdd_adam_multi)
         self.vq._packed = None
         return losses
 

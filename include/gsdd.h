@@ -270,8 +270,12 @@ int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out, void* str
  * L % 32 == 0 the forward runs on the matrix-pipe kernel of gsdd_d3pm_attention; workspace may be NULL (VALU kernel). */
 int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
                               void* workspace, int64_t workspace_bytes, void* stream);
+/* With a workspace of gsdd_d3pm_attention_bwd_workspace_bytes() and L % 32 == 0 the backward runs on the bf16 matrix pipe
+ * (pre-split operand images, dQ kernel + dK/dV kernel); otherwise on the VALU kernels, which need `scratch`. */
+int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H);
 int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
-                            int B, int L, int H, float* dqkv, float* scratch, void* stream);
+                            int B, int L, int H, float* dqkv, float* scratch, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 /* demb[tok] += dx, dpos[l] += dx */
 int gsdd_d3pm_embed_bwd(const float* dx, const int64_t* tok, int B, int L, int D, int n_embed, float* demb, float* dpos,
                         void* stream);
@@ -284,6 +288,9 @@ int gsdd_adaln_bwd(const float* dtab, const int64_t* t, int B, int D, const floa
 /* torch.optim.Adam update (no weight decay), step >= 1 */
 int gsdd_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
               void* stream);
+/* The same update over many tensors in one launch: table[b] = {p, g, m, v, n} (device pointers as int64, n <= 4096 elements) for
+ * block b; the caller chops every parameter into such chunks. */
+int gsdd_adam_multi(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, int step, void* stream);
 
 /* t[b] += dt ; stream[0] += ds   (device-side loop counters for the captured step graph) */
 int gsdd_advance(int64_t* t_dev, int B, int64_t dt, int64_t* stream_dev, int64_t ds, void* stream);

@@ -150,3 +150,32 @@ def test_two_rank_data_parallel_step_equals_global_batch(G, golden):
         d1, d2 = v - sd["transformer." + k], torch.from_numpy(got[k]) - sd["transformer." + k]
         big = want_g[k].abs() > 1e-2 * want_g[k].abs().max()
         assert torch.allclose(d1[big], d2[big], atol=5e-6, rtol=5e-2), k
+
+
+# ----------------------------------------------------------------------------- attention backward kernels vs fp64 autograd
+@pytest.mark.parametrize("valu", [False, True])
+@pytest.mark.parametrize("B,L,scale", [(2, 64, 1.0), (1, 320, 1.5), (1, 1024, 1.0), (2, 96, 3.0)])
+def test_attention_backward_matches_fp64_autograd(G, B, L, scale, valu, monkeypatch):
+    """dq | dk | dv of softmax(q k^T / 2) v for head dim 4: the matrix-pipe kernels (operand images, L % 32 == 0) and the VALU
+    kernels (no workspace) against torch.autograd in fp64.  L = 320 covers a partial 256-row chunk, scale 3 peaky attention."""
+    H = 16
+    g = torch.Generator().manual_seed(9)
+    q = (torch.randn(B, H, L, 4, generator=g) * scale).double().requires_grad_(True)
+    k = (torch.randn(B, H, L, 4, generator=g) * scale).double().requires_grad_(True)
+    v = torch.randn(B, H, L, 4, generator=g).double().requires_grad_(True)
+    dO = torch.randn(B, H, L, 4, generator=g).double()
+    o = torch.softmax((q @ k.transpose(-1, -2)) * 0.5, dim=-1) @ v
+    o.backward(dO)
+    hm = lambda z: z.detach().float().permute(1, 0, 2, 3).reshape(H, B * L, 4).contiguous().cuda()          # head-major rows
+    rm = lambda z: z.detach().float().permute(0, 2, 1, 3).reshape(B * L, H * 4).contiguous().cuda()         # [M][H*4]
+    qh, kh, vh = hm(q), hm(k), hm(v)
+    out = torch.empty((B * L, H * 4), device="cuda")
+    lse = torch.empty((H * B * L,), device="cuda")
+    G.ops.d3pm_attention_train(qh, kh, vh, B, L, H, out, lse, ws=G.ops.d3pm_attention_workspace(B, L, H, "cuda"))
+    torch.testing.assert_close(out.cpu().double(), rm(o).cpu().double(), atol=2e-5, rtol=0)
+    ws = None if valu else G.ops.d3pm_attention_bwd_workspace(B, L, H, "cuda")
+    dqkv = G.ops.d3pm_attention_bwd(qh, kh, vh, out, rm(dO), lse, B, L, H, ws=ws).cpu().double()
+    for name, got, want in (("dq", dqkv[:, :64], rm(q.grad)), ("dk", dqkv[:, 64:128], rm(k.grad)), ("dv", dqkv[:, 128:], rm(v.grad))):
+        want = want.cpu().double()
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err < 2e-5, f"{name}: relative max error {err:.3e}"
