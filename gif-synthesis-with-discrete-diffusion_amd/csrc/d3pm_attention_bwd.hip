@@ -171,7 +171,7 @@ struct DqSmem {
     uint4 ones[16];
 };
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const float* __restrict__ q, const float* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(const float* __restrict__ q, const float* __restrict__ o,
                                                                const float* __restrict__ dO, const float* __restrict__ lse,
                                                                BwdImages im, int B, int L, int H, float* __restrict__ dqkv) {
     __shared__ DqSmem sm;
@@ -295,7 +295,7 @@ struct DkvSmem {
     uint4 gv[2][BKC / 32][4][16];
 };
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ k, const float* __restrict__ v,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                                 BwdImages im, int B, int L, int H, float* __restrict__ dqkv) {
     extern __shared__ __attribute__((aligned(16))) char dkv_raw[];
     DkvSmem& sm = *reinterpret_cast<DkvSmem*>(dkv_raw);
@@ -323,7 +323,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
     }
 
     const int nchunks = (L + BKC - 1) / BKC;
-    uint4 r[10];
+    // staging registers are named scalars on purpose: an array captured by the lambdas is demoted to scratch memory (and the
+    // chunk's global loads are then waited for on the spot)
+    uint4 rq0, rq1, rq2, rg0, rg1, rg2, rqv0, rqv1, rgv0, rgv1;
     auto load_chunk = [&](int ch) {
         const int rows = min(BKC, L - ch * BKC);                      // multiple of 32
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -331,28 +333,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const float* __r
         const uint4* gs = im.gp + (hrow0 + (int64_t)ch * BKC) * 3;
         const uint4* qvs = im.qv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
         const uint4* gvs = im.gv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const bool ok = tid + 256 * i < rows * 3;
-            r[i] = ok ? qs[tid + 256 * i] : z;
-            r[3 + i] = ok ? gs[tid + 256 * i] : z;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = tid + 256 * i < rows * 2;
-            r[6 + i] = ok ? qvs[tid + 256 * i] : z;
-            r[8 + i] = ok ? gvs[tid + 256 * i] : z;
-        }
+        const bool a0 = tid < rows * 3, a1 = tid + 256 < rows * 3, a2 = tid + 512 < rows * 3;
+        const bool b0 = tid < rows * 2, b1 = tid + 256 < rows * 2;
+        rq0 = a0 ? qs[tid] : z; rq1 = a1 ? qs[tid + 256] : z; rq2 = a2 ? qs[tid + 512] : z;
+        rg0 = a0 ? gs[tid] : z; rg1 = a1 ? gs[tid + 256] : z; rg2 = a2 ? gs[tid + 512] : z;
+        rqv0 = b0 ? qvs[tid] : z; rqv1 = b1 ? qvs[tid + 256] : z;
+        rgv0 = b0 ? gvs[tid] : z; rgv1 = b1 ? gvs[tid + 256] : z;
     };
     auto store_chunk = [&](int buf) {
         uint4* qd = &sm.q[buf][0][0];
         uint4* gd = &sm.g[buf][0][0];
         uint4* qvd = &sm.qv[buf][0][0][0];
         uint4* gvd = &sm.gv[buf][0][0][0];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { qd[tid + 256 * i] = r[i]; gd[tid + 256 * i] = r[3 + i]; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { qvd[tid + 256 * i] = r[6 + i]; gvd[tid + 256 * i] = r[8 + i]; }
+        qd[tid] = rq0; qd[tid + 256] = rq1; qd[tid + 512] = rq2;
+        gd[tid] = rg0; gd[tid + 256] = rg1; gd[tid + 512] = rg2;
+        qvd[tid] = rqv0; qvd[tid + 256] = rqv1;
+        gvd[tid] = rgv0; gvd[tid + 256] = rgv1;
     };
 
     f32x4 acck[4], accv[4];

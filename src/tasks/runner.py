@@ -44,5 +44,5 @@ def train(cfg):
                 loss.backward()
                 for o in opts:
                     o.step()
-            print(f"epoch {epoch} step {i} loss {float(loss):.5f}")
+            print(f"epoch {epoch} step {i} loss {float(loss.detach()):.5f}")
     return {}
