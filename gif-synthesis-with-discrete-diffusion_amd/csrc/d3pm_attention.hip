@@ -578,11 +578,15 @@ extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
     return (int64_t)B * L * H * 64;          // 32 B (K pieces) + 32 B (V image) per key and head
 }
 
+int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
+                        void* stream);                                                              // d3pm_bwd.hip
+
 extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
                                    void* workspace, int64_t workspace_bytes, void* stream) {
     GSDD_CHECK_ARG(q && k && v && out, "null pointer");
-    GSDD_CHECK_ARG(B > 0 && H > 0 && L >= 16 && L % 16 == 0, "L must be a positive multiple of 16");
+    GSDD_CHECK_ARG(B > 0 && H > 0 && L > 0, "bad sizes");
     GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
+    if (L % 16 != 0) return gsdd_attention_valu(q, k, v, B, L, H, out, nullptr, stream);     // ragged lengths: VALU kernel
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
     static const bool force_v3 = getenv("GSDD_ATTN_V3") != nullptr;    // A/B switch: exact-f32 P.V (mfma 4x4x1) variant
     hipStream_t st = (hipStream_t)stream;

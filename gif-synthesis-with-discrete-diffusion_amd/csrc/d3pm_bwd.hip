@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* q, con
     if (ok) {
         const float inv = 1.f / l;
         *reinterpret_cast<float4*>(out + ((int64_t)b * L + qi) * (H * 4) + h * 4) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
-        lse[base + qi] = m + log2f(l);                       // log2 domain
+        if (lse != nullptr) lse[base + qi] = m + log2f(l);    // log2 domain
     }
 }
 
@@ -480,6 +480,14 @@ extern "C" int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out
 
 int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
                                void* workspace, int64_t workspace_bytes, void* stream, int* done);      // d3pm_attention.hip
+
+// any sequence length (one lane per query, keys broadcast from LDS): the sampler's fallback for L % 16 != 0
+int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse, void* stream) {
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((L + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, q, k, v, B, L, H,
+                       out, lse);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
 
 extern "C" int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
                                          float* lse, void* workspace, int64_t workspace_bytes, void* stream) {

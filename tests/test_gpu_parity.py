@@ -226,7 +226,8 @@ def attention_ref(q, k, v):
 
 
 @pytest.mark.parametrize("use_ws", [True, False])
-@pytest.mark.parametrize("B,L,spike", [(2, 64, False), (1, 1024, False), (2, 4096, False), (1, 512, True), (1, 48, False)])
+@pytest.mark.parametrize("B,L,spike", [(2, 64, False), (1, 1024, False), (2, 4096, False), (1, 512, True), (1, 48, False),
+                                       (2, 37, False), (1, 301, False)])          # ragged lengths take the VALU kernel
 def test_d3pm_attention(G, B, L, spike, use_ws):
     H = 16
     g = torch.Generator().manual_seed(5)
