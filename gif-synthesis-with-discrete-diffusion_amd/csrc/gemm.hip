@@ -11,6 +11,8 @@
 // Replaces (see include/gsdd.h): nn.Conv3d / nn.ConvTranspose3d (videogpt_vq_vae.py:289-332),
 // nn.Linear (model_utils.py:223-233, transformer_utils.py:36-43,258-263,353-356), BatchNorm(eval)+ReLU
 // folded as pro/epilogue (videogpt_vq_vae.py:125-133), LayerNorm apply (transformer_utils.py:157,217,354).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace gsdd {
@@ -25,18 +27,55 @@ struct GemmSmem {
     float b[2][BN][LDP];
 };
 
+// ---- bf16x3 variant: every f32 operand element is split error-free into three bf16 pieces (x = x1 + x2 + x3, 24 bits) when it
+// is staged into LDS, and a 32x32x16 k-step is the six significant cross products a1b1 a1b2 a2b1 a1b3 a2b2 a3b1 on
+// v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in the f32 accumulator; the dropped a2b3 + a3b2 + a3b3 are below
+// 2^-24 |a||b|): 6 x 32 cycles on the bf16 matrix pipe instead of 8 x 64 on the f32 datapath.  Same accumulator layout as
+// v_mfma_f32_32x32x2_f32, so prologues, epilogues and addressing are shared.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDPB = 40;                 // bf16 per LDS row (32 + 8 pad): 80-B pitch keeps the 16-B fragment reads conflict-free
+template <int BN>
+struct GemmSmemX3 {
+    uint16_t a[3][BM][LDPB];
+    uint16_t b[3][BN][LDPB];
+};
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 4 floats -> three pieces of 4 packed bf16 each (uint2): x = p[0] + p[1] + p[2]
+__device__ __forceinline__ void split3x4(const float4 v, uint2 (&p)[3]) {
+    float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t h01 = cvt_pk_bf16(x[0], x[1]), h23 = cvt_pk_bf16(x[2], x[3]);
+        p[i] = make_uint2(h01, h23);
+        if (i < 2) {
+            x[0] -= __uint_as_float(h01 << 16); x[1] -= __uint_as_float(h01 & 0xffff0000u);
+            x[2] -= __uint_as_float(h23 << 16); x[3] -= __uint_as_float(h23 & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf8(uint4 u) {
+    union { uint4 u; bf16x8 v; } c;
+    c.u = u;
+    return c.v;
+}
+
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return v * (1.f / (1.f + expf(-1.702f * v)));   // x * sigmoid(1.702 x)
     return v;
 }
 
-template <int BN>
+template <int BN, bool X3>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, const int64_t M) {
     constexpr int NT = BN / 64;          // 32-wide n tiles per wave
     constexpr int BJ = BN / 32;          // weight rows staged per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GemmSmem<BN>& sm = *reinterpret_cast<GemmSmem<BN>*>(smem_raw);
+    GemmSmemX3<BN>& sx = *reinterpret_cast<GemmSmemX3<BN>*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -134,13 +173,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
                 v.z = (v.z - mu[j]) * rs[j] * g.z + bt.z; v.w = (v.w - mu[j]) * rs[j] * g.w + bt.w;
             }
             if (!((okbits >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = v;
+            if constexpr (X3) {
+                uint2 pc[3];
+                split3x4(v, pc);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.a[i][r0 + 32 * j][4 * kq]) = pc[i];
+            } else {
+                *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             float4 v = rb[j];
             if (!((okbits >> (8 + j)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = v;
+            if constexpr (X3) {
+                uint2 pc[3];
+                split3x4(v, pc);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.b[i][r0 + 32 * j][4 * kq]) = pc[i];
+            } else {
+                *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = v;
+            }
         }
     };
 
@@ -156,6 +209,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
+    if constexpr (X3) {
+        // single LDS buffer: chunk i+1 waits in registers while chunk i's MFMAs run, and is split + staged between two barriers
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[2][3], bf[NT][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        af[mt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.a[i][wm * 64 + mt * 32 + li][16 * ks + 8 * lh]));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bf[nt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.b[i][wn * (BN / 2) + nt * 32 + li][16 * ks + 8 * lh]));
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][2], bf[nt][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][1], bf[nt][1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][2], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][1], bf[nt][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][0], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                               // every wave is done reading this chunk
+            if (chunk + 1 < nchunks) store_chunk(0);
+            __syncthreads();
+        }
+    } else {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         if (chunk + 1 < nchunks) load_chunk(chunk + 1);
@@ -180,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
         }
         if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
+    }
     }
 
     // ---- epilogue: lane holds column n = li, rows (r&3)+8*(r>>2)+4*lh of each 32x32 tile
@@ -307,12 +394,17 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
     GSDD_CHECK_ARG((int64_t)d->ntaps * d->Cout * d->Cin < (1ll << 31), "more than 2^31 weight elements");
     hipStream_t st = (hipStream_t)stream;
     const unsigned gx = (unsigned)((M + BM - 1) / BM);
+    // bf16x3 on the matrix pipe when the contraction is long enough to pay for the splits; GSDD_GEMM_F32=1 forces the f32 MFMA
+    static const bool force_f32 = getenv("GSDD_GEMM_F32") != nullptr;
+    const bool x3 = !force_f32 && (int64_t)d->ntaps * d->Cin >= 64;
     if (d->Cout > 64) {
         const dim3 grid(gx, (d->Cout + 127) / 128);
-        hipLaunchKernelGGL(gemm_kernel<128>, grid, dim3(256), sizeof(GemmSmem<128>), st, *d, M);
+        if (x3) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, dim3(256), sizeof(GemmSmemX3<128>), st, *d, M);
+        else hipLaunchKernelGGL((gemm_kernel<128, false>), grid, dim3(256), sizeof(GemmSmem<128>), st, *d, M);
     } else {
         const dim3 grid(gx, 1);
-        hipLaunchKernelGGL(gemm_kernel<64>, grid, dim3(256), sizeof(GemmSmem<64>), st, *d, M);
+        if (x3) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, dim3(256), sizeof(GemmSmemX3<64>), st, *d, M);
+        else hipLaunchKernelGGL((gemm_kernel<64, false>), grid, dim3(256), sizeof(GemmSmem<64>), st, *d, M);
     }
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
