@@ -2,6 +2,8 @@
 // BN+ReLU prologue, BatchNorm(train)+ReLU backward, ReLU masks, axial-attention backward, small elementwise helpers.
 // Data gradients of (transposed) convolutions reuse gsdd_gemm with transposed weights and mirrored tap tables.
 // Reference semantics: autograd of videogpt_vq_vae.py:102-138, 228-332 and model_utils.py:211-289, 318-337, 586-600.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace gsdd {
@@ -128,6 +130,167 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const gsdd_gemm_desc
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[b8 & 1][u], xb[b8 & 1][u], acc, 0, 0, 0);
             }
+        }
+        __syncthreads();                               // every wave is done with the tile
+        if (more) stage();
+    }
+    float* out = dW + (int64_t)tap * d.Cout * d.Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int c = c0 + wk * 32 + li;
+        if (n < d.Cout && c < d.Cin) atomicAdd(out + (int64_t)n * d.Cin + c, acc[r]);
+    }
+}
+
+// ------------------------------------------------------------------ conv weight gradient on the bf16 matrix pipe
+// Same contraction with both operands split error-free into three bf16 pieces (as gemm_kernel<.., true>): per 64-row slab a
+// 32x32 quadrant is 4 k-steps x 6 cross products of v_mfma_f32_32x32x16_bf16.  The MFMA wants 8 consecutive slab rows per
+// lane, so a thread stages an 8-row x 4-column patch: splitting pairs of rows packs them directly, and each (column, piece) is
+// one 16-byte LDS write into the transposed tile [piece][column][row] (pitch 72 bf16: conflict-free fragment reads; the
+// thread -> patch map keeps every 16-lane group of the writes on distinct banks too).
+constexpr int CX_ROWS = 64, CX_PITCH = 72;
+typedef __bf16 cw_bf16x8 __attribute__((ext_vector_type(8)));
+struct CwSmemX3 {
+    uint16_t t[2][3][64][CX_PITCH];          // [operand: dY | x][piece][column][slab row]
+    int src[2][CX_ROWS];
+    int dst[2][CX_ROWS];
+};
+__device__ __forceinline__ uint32_t cw_cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const gsdd_gemm_desc d, const float* dY, int dy_pitch, float* dW,
+                                                               const int64_t M, int slabs, int ctiles) {
+    extern __shared__ __attribute__((aligned(16))) char cwx_raw[];
+    CwSmemX3& sm = *reinterpret_cast<CwSmemX3*>(cwx_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = (blockIdx.y / ctiles) * 64, c0 = (blockIdx.y % ctiles) * 64;
+    const int tap = blockIdx.z;
+    const int wn = wave >> 1, wk = wave & 1;
+    int dt = 0, dh = 0, dw = 0;
+    if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
+    const bool linear_rows = (d.oD == d.Do && d.oH == d.Ho && d.oW == d.Wo && d.osd == 1 && d.osh == 1 && d.osw == 1 &&
+                              d.ood == 0 && d.ooh == 0 && d.oow == 0);
+    const int64_t slab0 = (int64_t)blockIdx.x * slabs;
+    int nsl = (int)((M - slab0 * CX_ROWS + CX_ROWS - 1) / CX_ROWS);
+    nsl = nsl < slabs ? nsl : slabs;
+    if (nsl <= 0) return;
+
+    // staging patch of this thread: operand op, columns 4*cgrp..+3, slab rows 8*rgrp..+7
+    const int op = tid >> 7, t7 = tid & 127;
+    const int cgrp = 4 * ((t7 >> 4) & 3) + (t7 & 3), rgrp = 4 * (t7 >> 6) + ((t7 >> 2) & 3);
+    const int c4 = 4 * cgrp;
+    const bool col_ok = op == 0 ? (n0 + c4 < d.Cout) : (c0 + c4 < d.Cin);
+    const int gcol = col_ok ? (op == 0 ? n0 + c4 : c0 + c4) : 0;
+    const float* gbase = op == 0 ? dY : d.in;
+    const int gpitch = op == 0 ? dy_pitch : d.in_pitch;
+    const bool has_pro = op == 1 && d.pro_scale != nullptr;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_pro) { ps = *reinterpret_cast<const float4*>(d.pro_scale + gcol); pb = *reinterpret_cast<const float4*>(d.pro_shift + gcol); }
+
+    auto decode = [&](int sl) {                       // one row per thread (threads 0..63)
+        if (tid < CX_ROWS) {
+            const int64_t m = (slab0 + sl) * CX_ROWS + tid;
+            int src = -1, dst = -1;
+            if (m < M) {
+                uint32_t q = (uint32_t)m;
+                const uint32_t wo = q % (uint32_t)d.Wo; q /= (uint32_t)d.Wo;
+                const uint32_t ho = q % (uint32_t)d.Ho; q /= (uint32_t)d.Ho;
+                const uint32_t to = q % (uint32_t)d.Do; q /= (uint32_t)d.Do;
+                dst = (int)m;
+                if (!linear_rows)
+                    dst = (((int)q * d.oD + ((int)to * d.osd + d.ood)) * d.oH + ((int)ho * d.osh + d.ooh)) * d.oW + ((int)wo * d.osw + d.oow);
+                const int ti = (int)to * d.sd + dt, hi = (int)ho * d.sh + dh, wi = (int)wo * d.sw + dw;
+                if ((unsigned)ti < (unsigned)d.Di && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
+                    src = (((int)q * d.Di + ti) * d.Hi + hi) * d.Wi + wi;
+            }
+            sm.src[sl & 1][tid] = src;
+            sm.dst[sl & 1][tid] = dst;
+        }
+    };
+    float4 v0, v1, v2, v3, v4, v5, v6, v7;            // named scalars: an array captured by the lambdas would live in scratch
+    unsigned okbits = 0;
+    auto issue = [&](int sl) {
+        const int* tab = op == 0 ? sm.dst[sl & 1] : sm.src[sl & 1];
+        okbits = 0;
+        const float* pp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = tab[8 * rgrp + i];
+            const bool ok = (row >= 0) & col_ok;
+            pp[i] = gbase + ((int64_t)(ok ? row : 0) * gpitch + gcol);
+            okbits |= (ok ? 1u : 0u) << i;
+        }
+        v0 = *reinterpret_cast<const float4*>(pp[0]); v1 = *reinterpret_cast<const float4*>(pp[1]);
+        v2 = *reinterpret_cast<const float4*>(pp[2]); v3 = *reinterpret_cast<const float4*>(pp[3]);
+        v4 = *reinterpret_cast<const float4*>(pp[4]); v5 = *reinterpret_cast<const float4*>(pp[5]);
+        v6 = *reinterpret_cast<const float4*>(pp[6]); v7 = *reinterpret_cast<const float4*>(pp[7]);
+    };
+    auto stage = [&]() {
+        float x[8][4];
+        const float4 vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 v = vv[i];
+            if (has_pro) {
+                v.x = fmaxf(fmaf(v.x, ps.x, pb.x), 0.f); v.y = fmaxf(fmaf(v.y, ps.y, pb.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, ps.z, pb.z), 0.f); v.w = fmaxf(fmaf(v.w, ps.w, pb.w), 0.f);
+            }
+            if (!((okbits >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                   // column 4*cgrp + j: 8 consecutive slab rows -> one uint4 per piece
+            float r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = x[i][j];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    w[i2] = cw_cvt_pk_bf16(r[2 * i2], r[2 * i2 + 1]);
+                    if (pc < 2) {
+                        r[2 * i2] -= __uint_as_float(w[i2] << 16);
+                        r[2 * i2 + 1] -= __uint_as_float(w[i2] & 0xffff0000u);
+                    }
+                }
+                *reinterpret_cast<uint4*>(&sm.t[op][pc][c4 + j][8 * rgrp]) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    decode(0);
+    __syncthreads();
+    issue(0);
+    stage();
+    for (int sl = 0; sl < nsl; ++sl) {
+        const bool more = sl + 1 < nsl;
+        if (more) decode(sl + 1);
+        __syncthreads();                               // tile of slab sl staged, row table of slab sl+1 visible
+        if (more) issue(sl + 1);
+#pragma unroll
+        for (int ks = 0; ks < CX_ROWS / 16; ++ks) {
+            cw_bf16x8 yf[3], xf[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                union { uint4 u; cw_bf16x8 v; } a, b;
+                a.u = *reinterpret_cast<const uint4*>(&sm.t[0][pc][wn * 32 + li][16 * ks + 8 * lh]);
+                b.u = *reinterpret_cast<const uint4*>(&sm.t[1][pc][wk * 32 + li][16 * ks + 8 * lh]);
+                yf[pc] = a.v; xf[pc] = b.v;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[2], xf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[1], xf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[1], xf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[0], acc, 0, 0, 0);
         }
         __syncthreads();                               // every wave is done with the tile
         if (more) stage();
@@ -292,15 +455,21 @@ extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_
     GSDD_CHECK_ARG((int64_t)d->N * d->Di * d->Hi * d->Wi < (1ll << 31), "more than 2^31 input rows");
     GSDD_CHECK_ARG(d->oD > 0 && d->oH > 0 && d->oW > 0 && (int64_t)d->N * d->oD * d->oH * d->oW < (1ll << 31), "bad output dims");
     const int ntiles = (d->Cout + 63) / 64, ctiles = (d->Cin + 63) / 64;
+    static const bool force_f32 = getenv("GSDD_GEMM_F32") != nullptr;
+    const int rows_per_slab = force_f32 ? CW_ROWS : CX_ROWS;
     // rows per block: enough blocks to fill the chip (>= ~2048), as few atomics per dW element as that allows
-    const int64_t nslabs = (M + CW_ROWS - 1) / CW_ROWS;
+    const int64_t nslabs = (M + rows_per_slab - 1) / rows_per_slab;
     const int64_t per_x = (int64_t)ntiles * ctiles * d->ntaps;
     int64_t gx = (2048 + per_x - 1) / per_x;
     gx = gx < 1 ? 1 : (gx > nslabs ? nslabs : gx);
     int slabs = (int)((nslabs + gx - 1) / gx);
-    slabs = slabs < 8 ? (nslabs < 8 ? (int)nslabs : 8) : (slabs > 64 ? 64 : slabs);
+    slabs = slabs < 8 ? (nslabs < 8 ? (int)nslabs : 8) : (slabs > 128 ? 128 : slabs);
     const dim3 grid((unsigned)((nslabs + slabs - 1) / slabs), ntiles * ctiles, d->ntaps);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), sizeof(CwSmem), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
+    if (force_f32)
+        hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), sizeof(CwSmem), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
+    else
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(256), sizeof(CwSmemX3), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs,
+                           ctiles);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }
