@@ -450,7 +450,7 @@ class DiffusionTransformer(nn.Module):
     @torch.no_grad()
     def _train_loss(self, x, cond_emb, is_train=True, want_probs=True):
         """_train_loss (diffusion_transformer.py:391-457) as HIP kernels: q_sample -> denoiser -> fused KL/NLL/aux
-        reduction.  Forward value only: there is no backward on the HIP path yet, so nothing here records a graph."""
+        reduction (forward value; the gradient path is d3pm_train.py, reached through forward() when autograd is enabled)."""
         dev = x.device
         B, L = x.shape
         K, T = self.num_classes - 1, self.num_timesteps
@@ -476,15 +476,23 @@ class DiffusionTransformer(nn.Module):
 
     def forward(self, input, return_loss=False, return_logits=True, return_att_weight=False, is_train=True, **kwargs):
         """diffusion_transformer.py:520-565 -> {'logits': exp(log_model_prob) (B,K+1,L), 'loss', 'pred_data' (B,L)}."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.transformer.parameters()) and self.training:
-            raise NotImplementedError("the D3PM backward pass is not built on the HIP path yet: evaluate the training "
-                                      "objective under torch.no_grad() / .eval()")
         tok = input["content_token"]
         if not tok.is_cuda:
             raise GsddError("the HIP path needs tensors on a ROCm device (no CPU fallback)")
         cond = input.get("condition_embed_token")
         if cond is None:
             raise NotImplementedError("cond_emb=None is not used by the reference call sites")
+        if torch.is_grad_enabled() and is_train and self.training and any(p.requires_grad for p in self.transformer.parameters()):
+            # the loss carries a grad_fn into the HIP backward (d3pm_train.py): loss.backward() fills the transformer's .grad
+            from .d3pm_train import train_forward
+            loss, r = train_forward(self, tok, cond.float(), want_probs=return_logits)
+            out = {"pred_data": r["x0_recon"]}
+            if return_logits:
+                out["logits"] = r["probs"]
+            if return_loss:
+                out["loss"] = loss
+            self.last_train_stats = r
+            return out
         out = {}
         if is_train:
             r = self._train_loss(tok, cond.float(), is_train=True, want_probs=return_logits)

@@ -64,8 +64,9 @@ class D3PMTrainer:
 
     # ------------------------------------------------------------------ loss + gradients
     @torch.no_grad()
-    def loss_and_grads(self, x0, cond, t=None, pt=None):
-        """-> (loss tensor [1], {state_dict name: gradient}) for the transformer's parameters."""
+    def loss_and_grads(self, x0, cond, t=None, pt=None, want_probs=False):
+        """-> (loss tensor [1], {state_dict name: gradient}) for the transformer's parameters.  The gradients are views of one
+        arena that the next call re-uses; `self.last_fwd` keeps the forward's dict (x0_recon, per_sample, probs if asked)."""
         dm, tr = self.dm, self.dm.transformer
         if not x0.is_cuda:
             raise GsddError("the HIP path needs tensors on a ROCm device (no CPU fallback)")
@@ -87,7 +88,9 @@ class D3PMTrainer:
         sv = self._forward(xt, cond, t)
         kw = dict(K=K, T=T, mask_weight=dm.mask_weight, aux_weight=dm.auxiliary_loss_weight,
                   adaptive_aux=dm.adaptive_auxiliary_loss)
-        fwd = ops.d3pm_train_loss(sv["logits"], x0, xt, t, pt, sched, dm.Lt_history, dm.Lt_count, want_probs=False, **kw)
+        fwd = ops.d3pm_train_loss(sv["logits"], x0, xt, t, pt, sched, dm.Lt_history, dm.Lt_count, want_probs=want_probs, **kw)
+        fwd["t"], fwd["xt"] = t, xt
+        self.last_fwd = fwd
         dlogits = ops.d3pm_train_loss_bwd(sv["logits"], x0, xt, t, pt, sched, **kw)
 
         g = {}
@@ -185,3 +188,33 @@ class D3PMTrainer:
         self._adam.step(grads)                  # all parameters in one launch
         tr._packed = None                       # parameters changed in place through raw pointers
         return loss
+
+
+class _TrainForward(torch.autograd.Function):
+    """Bridges the HIP training objective into torch.autograd so that the reference's stage-2 loop (zero_grad, manual_backward(loss),
+    optimizer.step(): multistage_text_motion_model.py:186-197) runs unchanged: forward evaluates loss and gradients on the HIP path
+    (one fused pass: the activations never outlive it), backward hands each transformer parameter its gradient scaled by the
+    incoming d(loss)."""
+
+    @staticmethod
+    def forward(ctx, trainer, x0, cond, want_probs, *params):
+        loss, grads = trainer.loss_and_grads(x0, cond, want_probs=want_probs)
+        names = [n for n, _ in trainer.dm.transformer.named_parameters()]
+        ctx.grads = [grads[n].clone() for n in names]          # the arena is re-used by the next forward
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        out = tuple(g * g_loss for g in ctx.grads)
+        ctx.grads = None
+        return (None, None, None, None) + out
+
+
+def train_forward(dm, x0, cond, want_probs=False):
+    """DiffusionTransformer.forward in train mode with autograd enabled -> (loss with grad_fn, forward dict)."""
+    tr = getattr(dm, "_hip_trainer", None)
+    if tr is None:
+        tr = D3PMTrainer(dm)
+        object.__setattr__(dm, "_hip_trainer", tr)
+    loss = _TrainForward.apply(tr, x0, cond, want_probs, *[p for _, p in dm.transformer.named_parameters()])
+    return loss, tr.last_fwd

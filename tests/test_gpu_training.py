@@ -179,3 +179,27 @@ def test_attention_backward_matches_fp64_autograd(G, B, L, scale, valu, monkeypa
         want = want.cpu().double()
         err = (got - want).abs().max().item() / want.abs().max().item()
         assert err < 2e-5, f"{name}: relative max error {err:.3e}"
+
+
+def test_d3pm_forward_backward_through_autograd_bridge(G, golden):
+    """The reference's stage-2 loop calls manual_backward(loss) on DiffusionTransformer.forward's loss
+    (multistage_text_motion_model.py:186-197): in train mode with autograd enabled the loss must carry a grad_fn that fills
+    every transformer .grad with the HIP gradients (scaled by the incoming d(loss))."""
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    sd, a, cfg = golden("d3pm_L64")
+    x0, cond = torch.from_numpy(a["train_x0"]).cuda(), torch.from_numpy(a["step_cond"]).cuda()
+    dm = build(G, sd, cfg).train()
+    dm.set_noise(cfg["noise_seed"], stream=int(a["train_stream"]))
+    torch.manual_seed(0)
+    out = dm({"content_token": x0, "condition_embed_token": cond}, return_loss=True)
+    assert out["loss"].requires_grad and tuple(out["logits"].shape) == (cfg["B"], cfg["K"] + 1, cfg["L"])
+    (2.0 * out["loss"]).backward()
+    t_used = dm.last_train_stats["t"]
+    ref = build(G, sd, cfg).train()
+    ref.set_noise(cfg["noise_seed"], stream=int(a["train_stream"]))
+    pt = torch.ones(cfg["B"], device="cuda") / cfg["T"]
+    loss, want = D3PMTrainer(ref).loss_and_grads(x0, cond, t=t_used, pt=pt)
+    np.testing.assert_allclose(out["loss"].item(), loss.item(), rtol=1e-6)
+    for name, prm in dm.transformer.named_parameters():
+        assert prm.grad is not None, name
+        torch.testing.assert_close(prm.grad, 2.0 * want[name], rtol=1e-5, atol=1e-8, msg=lambda s, n=name: f"{n}: {s}")
