@@ -33,12 +33,11 @@ struct GemmSmem {
 // 2^-24 |a||b|): 6 x 32 cycles on the bf16 matrix pipe instead of 8 x 64 on the f32 datapath.  Same accumulator layout as
 // v_mfma_f32_32x32x2_f32, so prologues, epilogues and addressing are shared.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BKX = 16;                  // k per chunk of the bf16x3 variant = one 32x32x16 k-step
-constexpr int LDPB = 24;                 // bf16 per LDS row (16 + 8 pad): 48-B pitch keeps the 16-B fragment reads conflict-free
+constexpr int LDPB = 40;                 // bf16 per LDS row (32 + 8 pad): 80-B pitch keeps the 16-B fragment reads conflict-free
 template <int BN>
 struct GemmSmemX3 {
-    uint16_t a[2][3][BM][LDPB];
-    uint16_t b[2][3][BN][LDPB];
+    uint16_t a[3][BM][LDPB];
+    uint16_t b[3][BN][LDPB];
 };
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     uint32_t r;
@@ -73,11 +72,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 template <int BN, bool X3>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, const int64_t M) {
     constexpr int NT = BN / 64;          // 32-wide n tiles per wave
-    constexpr int BKc = X3 ? BKX : BK;   // k per chunk
-    constexpr int KQN = BKc / 4;         // float4 per row and chunk
-    constexpr int RSTEP = 256 / KQN;     // rows staged per pass of the 256 threads
-    constexpr int RA = BM / RSTEP;       // activation rows staged per thread
-    constexpr int BJ = BN / RSTEP;       // weight rows staged per thread
+    constexpr int BJ = BN / 32;          // weight rows staged per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GemmSmem<BN>& sm = *reinterpret_cast<GemmSmem<BN>*>(smem_raw);
     GemmSmemX3<BN>& sx = *reinterpret_cast<GemmSmemX3<BN>*>(smem_raw);
@@ -86,16 +81,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t bm0 = (int64_t)blockIdx.x * BM;
     const int bn0 = blockIdx.y * BN;
-    const int kq = tid % KQN, r0 = tid / KQN;
+    const int kq = tid & 7, r0 = tid >> 3;
 
     // ---- per-thread staged rows of the activation operand (row index and tap-free coordinates, all 32-bit)
-    int ti0[RA], hi0[RA], wi0[RA], rbase[RA];
-    bool rvalid[RA];
-    float mu[RA], rs[RA];
-    int64_t sel[RA];
+    int ti0[4], hi0[4], wi0[4], rbase[4];
+    bool rvalid[4];
+    float mu[4], rs[4];
+    int64_t sel[4];
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        const int64_t m = bm0 + r0 + RSTEP * j;
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = bm0 + r0 + 32 * j;
         rvalid[j] = m < M;
         const uint32_t mm = rvalid[j] ? (uint32_t)m : 0u;          // M < 2^31 (checked on the host)
         if (d.gather != nullptr) {
@@ -116,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
         }
     }
 
-    const int cchunks = (d.Cin + BKc - 1) / BKc;
+    const int cchunks = (d.Cin + BK - 1) / BK;
     const int nchunks = d.ntaps * cchunks;
     const bool has_pro = d.pro_scale != nullptr;
     const float* pro_s = has_pro ? d.pro_scale : d.w;          // always-dereferenceable pointers: the loads below are
@@ -125,12 +120,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     // Global loads of chunk i+1 are issued before the MFMAs of chunk i and consumed after them.  They are branch-free
     // (out-of-range rows / channels read a clamped, valid address and are zeroed when staged into LDS): a load under an
     // exec-masked branch makes the compiler wait for it on the spot, which serialises memory latency with the MFMAs.
-    float4 ra[RA], rb[BJ], ps, pb;
+    float4 ra[4], rb[BJ], ps, pb;
     unsigned okbits = 0;
     int cc = 0;
     auto load_chunk = [&](int chunk) {
         const int tap = chunk / cchunks;
-        const int c = (chunk - tap * cchunks) * BKc + 4 * kq;
+        const int c = (chunk - tap * cchunks) * BK + 4 * kq;
         const bool cvalid = c < d.Cin;
         cc = cvalid ? c : 0;
         int dt = 0, dh = 0, dw = 0;
@@ -139,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
         ps = *reinterpret_cast<const float4*>(pro_s + cc);
         pb = *reinterpret_cast<const float4*>(pro_b + cc);
         okbits = 0;
-        const float* pa[RA];
+        const float* pa[4];
         const float* pw[BJ];
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
             const bool ok = rvalid[j] & cvalid & ((unsigned)ti < (unsigned)d.Di) & ((unsigned)hi < (unsigned)d.Hi) &
                             ((unsigned)wi < (unsigned)d.Wi);
@@ -153,19 +148,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
         const int wrow0 = tap * d.Cout;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int n = bn0 + r0 + RSTEP * j;
+            const int n = bn0 + r0 + 32 * j;
             const bool ok = (n < d.Cout) & cvalid;
             pw[j] = d.w + (uint32_t)((wrow0 + (ok ? n : 0)) * d.Cin + cc);           // weights hold < 2^31 elements (host check)
             okbits |= (ok ? 1u : 0u) << (8 + j);
         }
 #pragma unroll
-        for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j]);
+        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j]);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const float4*>(pw[j]);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
+        for (int j = 0; j < 4; ++j) {
             float4 v = ra[j];
             if (has_pro) {
                 v.x = fmaxf(fmaf(v.x, ps.x, pb.x), 0.f); v.y = fmaxf(fmaf(v.y, ps.y, pb.y), 0.f);
@@ -182,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
                 uint2 pc[3];
                 split3x4(v, pc);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.a[buf][i][r0 + RSTEP * j][4 * kq]) = pc[i];
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.a[i][r0 + 32 * j][4 * kq]) = pc[i];
             } else {
-                *reinterpret_cast<float4*>(&sm.a[buf][r0 + RSTEP * j][4 * kq]) = v;
+                *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = v;
             }
         }
 #pragma unroll
@@ -195,9 +190,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
                 uint2 pc[3];
                 split3x4(v, pc);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.b[buf][i][r0 + RSTEP * j][4 * kq]) = pc[i];
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.b[i][r0 + 32 * j][4 * kq]) = pc[i];
             } else {
-                *reinterpret_cast<float4*>(&sm.b[buf][r0 + RSTEP * j][4 * kq]) = v;
+                *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = v;
             }
         }
     };
@@ -215,34 +210,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     store_chunk(0);
     __syncthreads();
     if constexpr (X3) {
-        // one 32x32x16 k-step per chunk, double-buffered LDS: after a chunk's 6 MFMAs per tile are issued the matrix pipe runs
-        // them while this wave splits and stages chunk i+1 (waiting in registers) into the other buffer and requests chunk i+2
-        if (nchunks > 1) load_chunk(1);
+        // single LDS buffer: chunk i+1 waits in registers while chunk i's MFMAs run, and is split + staged between two barriers
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int buf = chunk & 1;
-            bf16x8 af[2][3], bf[NT][3];
+            if (chunk + 1 < nchunks) load_chunk(chunk + 1);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[2][3], bf[NT][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        af[mt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.a[i][wm * 64 + mt * 32 + li][16 * ks + 8 * lh]));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bf[nt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.b[i][wn * (BN / 2) + nt * 32 + li][16 * ks + 8 * lh]));
+                }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    af[mt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.a[buf][i][wm * 64 + mt * 32 + li][8 * lh]));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bf[nt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.b[buf][i][wn * (BN / 2) + nt * 32 + li][8 * lh]));
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][2], bf[nt][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][1], bf[nt][1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][2], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][1], bf[nt][0], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][0], acc[mt][nt], 0, 0, 0);
+                    }
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][2], bf[nt][0], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][1], bf[nt][1], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][2], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][1], bf[nt][0], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][1], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][0], bf[nt][0], acc[mt][nt], 0, 0, 0);
-                }
-            if (chunk + 1 < nchunks) store_chunk(buf ^ 1);
-            if (chunk + 2 < nchunks) load_chunk(chunk + 2);
+            __syncthreads();                               // every wave is done reading this chunk
+            if (chunk + 1 < nchunks) store_chunk(0);
             __syncthreads();
         }
     } else {
