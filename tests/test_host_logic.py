@@ -201,3 +201,63 @@ def test_clip_folder_dataset_enumerates_like_the_reference(tmp_path):
     assert got == [("Archery", 0), ("Swing", 0), ("Swing", 100)]            # Biking is shorter than one window
     item = ds[2]
     assert item["label"] == 2 and item["text"] == "Swing" and tuple(item["frames"].shape) == (16, 6, 8, 3)
+
+
+# ----------------------------------------------------------------------------- sub-pixel phase tables vs brute force (1-D, separable)
+def _same_pad(k, s):
+    total = k - s
+    return total // 2 + total % 2          # pad_front of SamePadConv3d / SamePadConvTranspose3d (videogpt_vq_vae.py:295-300, 318-323)
+
+
+@pytest.mark.parametrize("k,s", [(4, 2), (4, 1), (3, 1), (1, 1), (5, 2), (6, 3), (2, 2)])
+def test_conv_dgrad_phases_are_the_adjoint_of_the_strided_conv(k, s):
+    """conv_dgrad_phases (VQ-VAE trainer): dIn computed phase by phase over the input grid == the brute-force adjoint of
+    out[o] = sum_kk w[kk] in[o*s + kk - pf] (zero padding)."""
+    import numpy as np
+    from gsdd_amd.vqvae_trainer import conv_dgrad_phases
+    rng = np.random.default_rng(k * 10 + s)
+    n_out = 5
+    n_in = n_out * s
+    pf = _same_pad(k, s)
+    w, dout = rng.standard_normal(k), rng.standard_normal(n_out)
+    want = np.zeros(n_in)
+    for o in range(n_out):
+        for kk in range(k):
+            i = o * s + kk - pf
+            if 0 <= i < n_in:
+                want[i] += w[kk] * dout[o]
+    got = np.zeros(n_in)
+    for (phase, ks, offs) in conv_dgrad_phases((k, 1, 1), (s, 1, 1), (pf, 0, 0)):
+        p = phase[0]
+        for ic in range(n_in // s):                      # coarse input index: fine index ic*s + p
+            for (kk, _, _), (off, _, _) in zip(ks, offs):
+                o = ic + off
+                if 0 <= o < n_out:
+                    got[ic * s + p] += w[kk] * dout[o]
+    np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+@pytest.mark.parametrize("k,s", [(4, 2), (4, 1), (3, 1), (5, 3), (1, 1)])     # the reference layer is size-preserving only for s == 1 or k == s + 2
+def test_convT_phases_reproduce_conv_transpose(k, s):
+    """convT_phases: out[o'*s + p] = sum_taps w[kk] in[o' + off] == F.conv_transpose1d on the front/back padded input with
+    padding = k - 1 (SamePadConvTranspose3d, videogpt_vq_vae.py:312-332)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from gsdd_amd.vqvae import convT_phases
+    rng = np.random.default_rng(k * 7 + s)
+    n_in = 6
+    pf = _same_pad(k, s)
+    pb = (k - s) // 2
+    w, x = rng.standard_normal(k), rng.standard_normal(n_in)
+    xp = F.pad(torch.from_numpy(x).view(1, 1, -1), (pf, pb))
+    want = F.conv_transpose1d(xp, torch.from_numpy(w).view(1, 1, -1), stride=s, padding=k - 1).view(-1).numpy()
+    assert want.shape[0] == n_in * s
+    got = np.zeros(n_in * s)
+    for (phase, ks, offs) in convT_phases((k, 1, 1), (s, 1, 1), (pf, 0, 0)):
+        p = phase[0]
+        for oc in range(n_in):
+            for (kk, _, _), (off, _, _) in zip(ks, offs):
+                i = oc + off
+                if 0 <= i < n_in:
+                    got[oc * s + p] += w[kk] * x[i]
+    np.testing.assert_allclose(got, want, atol=1e-12)
