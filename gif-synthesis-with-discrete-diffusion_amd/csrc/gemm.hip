@@ -123,28 +123,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     float4 ra[4], rb[BJ], ps, pb;
     unsigned okbits = 0;
     int cc = 0;
-    auto load_chunk = [&](int chunk) {
-        const int tap = chunk / cchunks;
-        const int c = (chunk - tap * cchunks) * BK + 4 * kq;
+    // Chunks are requested in order, so (tap, channel chunk) is a running counter, and everything that depends on the tap alone
+    // (source row, bounds test) is computed once per tap and re-used by its channel chunks.
+    int ld_tap = 0, ld_cq = 0;
+    const float* prow[4];
+    unsigned rowok = 0;
+    auto load_chunk = [&](int /*chunk: always the next one*/) {
+        const int tap = ld_tap;
+        if (ld_cq == 0) {
+            int dt = 0, dh = 0, dw = 0;
+            if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
+            const int tapoff = (dt * d.Hi + dh) * d.Wi + dw;
+            rowok = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
+                const bool ok = rvalid[j] & ((unsigned)ti < (unsigned)d.Di) & ((unsigned)hi < (unsigned)d.Hi) &
+                                ((unsigned)wi < (unsigned)d.Wi);
+                const int row = ok ? rbase[j] + tapoff : 0;
+                prow[j] = d.in + (int64_t)row * d.in_pitch;
+                rowok |= (ok ? 1u : 0u) << j;
+            }
+        }
+        const int c = ld_cq * BK + 4 * kq;
         const bool cvalid = c < d.Cin;
         cc = cvalid ? c : 0;
-        int dt = 0, dh = 0, dw = 0;
-        if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
-        const int tapoff = (dt * d.Hi + dh) * d.Wi + dw;
+        if (++ld_cq == cchunks) { ld_cq = 0; ++ld_tap; }
         ps = *reinterpret_cast<const float4*>(pro_s + cc);
         pb = *reinterpret_cast<const float4*>(pro_b + cc);
-        okbits = 0;
+        okbits = cvalid ? rowok : 0u;
         const float* pa[4];
         const float* pw[BJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
-            const bool ok = rvalid[j] & cvalid & ((unsigned)ti < (unsigned)d.Di) & ((unsigned)hi < (unsigned)d.Hi) &
-                            ((unsigned)wi < (unsigned)d.Wi);
-            const int row = ok ? rbase[j] + tapoff : 0;
-            pa[j] = d.in + ((int64_t)row * d.in_pitch + cc);
-            okbits |= (ok ? 1u : 0u) << j;
-        }
+        for (int j = 0; j < 4; ++j) pa[j] = prow[j] + cc;
         const int wrow0 = tap * d.Cout;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
