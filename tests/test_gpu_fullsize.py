@@ -69,11 +69,12 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
     assert mism.sum().item() <= 2, f"{mism.sum().item()} of {L} tokens differ"
 
 
-def test_full_size_vqvae_encode_decode(G):
+@pytest.mark.parametrize("res", [128, 64])      # C2's clip shape, and config C1 (one 16x64x64 clip, encode -> quantise -> decode)
+def test_full_size_vqvae_encode_decode(G, res):
     from oracle import vqvae as ov
     torch.manual_seed(0)
     cfg = dict(embedding_dim=128, n_codes=4096, n_hiddens=256, n_res_layers=3, downsample=[1, 8, 8], sequence_length=16,
-               resolution=128)
+               resolution=res)
     m = G.VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"], cfg["downsample"],
                 cfg["sequence_length"], cfg["resolution"]).eval()
     g = torch.Generator().manual_seed(1)
@@ -84,12 +85,14 @@ def test_full_size_vqvae_encode_decode(G):
             mod.weight.data = 1.0 + 0.2 * torch.randn(mod.weight.shape, generator=g)
             mod.bias.data = 0.1 * torch.randn(mod.bias.shape, generator=g)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    x = torch.randn(1, 3, 16, 128, 128, generator=g)
+    x = torch.randn(1, 3, 16, res, res, generator=g)
     with torch.no_grad():
         z_ref = ov.pre_vq(x, sd, cfg)
         # spread the codebook over the latents so the arg-min is not degenerate
         flat = z_ref.permute(0, 2, 3, 4, 1).reshape(-1, 128)
-        sd["codebook.embeddings"] = flat[torch.randperm(flat.shape[0], generator=g)[:4096]] + 0.05 * torch.randn(4096, 128, generator=g)
+        pick = torch.randperm(flat.shape[0], generator=g)[:4096]
+        pick = pick if pick.numel() == 4096 else pick.repeat(4096 // pick.numel() + 1)[:4096]     # C1 has 1024 latents
+        sd["codebook.embeddings"] = flat[pick] + 0.05 * torch.randn(4096, 128, generator=g)
         idx_ref, d = ov.nearest_code(z_ref, sd["codebook.embeddings"])
         rec_ref = ov.decode(idx_ref, sd, cfg)
     m.load_state_dict(sd)
@@ -102,9 +105,9 @@ def test_full_size_vqvae_encode_decode(G):
     margin = (top2[:, 1] - top2[:, 0])
     mism = (idx != idx_ref).view(-1)
     assert not (mism & (margin > 1e-3)).any()
-    assert mism.sum().item() <= 4, f"{mism.sum().item()} of 4096 code indices differ"
+    assert mism.sum().item() <= 4, f"{mism.sum().item()} of {mism.numel()} code indices differ"
     rec = m.decode(idx_ref.cuda()).cpu()
-    assert tuple(rec.shape) == (1, 3, 16, 128, 128)
+    assert tuple(rec.shape) == (1, 3, 16, res, res)
     rerr = (rec - rec_ref).abs().max().item()
     assert rerr < 2e-4, rerr
     # property: decode is batch-independent and deterministic
