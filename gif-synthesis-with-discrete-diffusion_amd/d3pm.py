@@ -7,7 +7,6 @@ reference's names; the sampling loop runs as one captured
 step, replayed diffusion_step times with the timestep and the Philox stream id living in device memory.
 """
 import contextlib
-import math
 
 import torch
 import torch.nn as nn

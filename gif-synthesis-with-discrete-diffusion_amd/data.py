@@ -4,7 +4,6 @@ import math
 
 import torch
 
-from . import ops
 from ._lib import GsddError, check, lib, ptr, stream_ptr
 
 

@@ -7,7 +7,6 @@ import torch
 from ._lib import GemmDesc, LayerDesc, StepDesc, TrainDesc, check, lib, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_GELU2 = 0, 1, 2
-_keep = []          # tap tables are tiny device tensors that must outlive the launch
 
 
 def taps_tensor(taps, device):
