@@ -124,3 +124,17 @@ def test_preprocess_oracle_matches_reference_function():
         out = op.preprocess(z[f"in{i}"], r, None if sl < 0 else sl)
         assert out.shape == z[f"out{i}"].shape
         np.testing.assert_allclose(out, z[f"out{i}"], atol=1e-6, rtol=0)
+
+
+def test_frechet_distance_matches_reference_function():
+    """gsdd_amd.metrics.frechet_distance against values returned by the reference's frechet_distance (evaluator.py:166-179) on
+    three feature-set pairs (different sample counts, dimension == sample count, shifted means)."""
+    import os
+    from tests.conftest import GOLDEN
+    from gsdd_amd.metrics import frechet_distance
+    z = np.load(os.path.join(GOLDEN, "frechet.npz"))
+    for i in range(3):
+        got = frechet_distance(torch.from_numpy(z[f"a{i}"]), torch.from_numpy(z[f"b{i}"])).item()
+        np.testing.assert_allclose(got, float(z[f"fd{i}"]), rtol=2e-4)      # fp32 SVDs of ill-conditioned covariance products
+    x = torch.from_numpy(z["a1"])
+    assert abs(frechet_distance(x, x.clone()).item()) < 1e-2 * float(z["fd1"])
