@@ -21,9 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BK = 32, LDP = 36;
 
-template <int BN>
+template <int BN, int BMt = BM>
 struct GemmSmem {
-    float a[2][BM][LDP];
+    float a[2][BMt][LDP];
     float b[2][BN][LDP];
 };
 
@@ -34,9 +34,9 @@ struct GemmSmem {
 // v_mfma_f32_32x32x2_f32, so prologues, epilogues and addressing are shared.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDPB = 40;                 // bf16 per LDS row (32 + 8 pad): 80-B pitch keeps the 16-B fragment reads conflict-free
-template <int BN>
+template <int BN, int BMt = BM>
 struct GemmSmemX3 {
-    uint16_t a[3][BM][LDPB];
+    uint16_t a[3][BMt][LDPB];
     uint16_t b[3][BN][LDPB];
 };
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
@@ -69,17 +69,23 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
-template <int BN, bool X3>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, const int64_t M) {
+// Block tile BMt x BN, NTH threads = NTH/64 waves laid out (BMt/64) x 2, each wave 64 x BN/2.  BMt = 128 (256 threads, two
+// blocks per CU) everywhere except the big bf16x3 convolutions, which take BMt = 256 (512 threads, one block per CU): the weight
+// tile is staged once per 256 rows, a quarter less L2 traffic and staging work per MAC.
+template <int BN, bool X3, int BMt = BM, int NTH = 256>
+__global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_desc d, const int64_t M) {
     constexpr int NT = BN / 64;          // 32-wide n tiles per wave
-    constexpr int BJ = BN / 32;          // weight rows staged per thread
+    constexpr int RSTEP = NTH / 8;       // rows staged per pass of the block's threads (8 threads per 32-k row)
+    constexpr int RA = BMt / RSTEP;      // activation rows staged per thread
+    constexpr int BJ = BN / RSTEP;       // weight rows staged per thread
+    static_assert(RA == 4, "the staging code below is written for 4 activation rows per thread");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    GemmSmem<BN>& sm = *reinterpret_cast<GemmSmem<BN>*>(smem_raw);
-    GemmSmemX3<BN>& sx = *reinterpret_cast<GemmSmemX3<BN>*>(smem_raw);
+    GemmSmem<BN, BMt>& sm = *reinterpret_cast<GemmSmem<BN, BMt>*>(smem_raw);
+    GemmSmemX3<BN, BMt>& sx = *reinterpret_cast<GemmSmemX3<BN, BMt>*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t bm0 = (int64_t)blockIdx.x * BM;
+    const int64_t bm0 = (int64_t)blockIdx.x * BMt;
     const int bn0 = blockIdx.y * BN;
     const int kq = tid & 7, r0 = tid >> 3;
 
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
     int64_t sel[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int64_t m = bm0 + r0 + 32 * j;
+        const int64_t m = bm0 + r0 + RSTEP * j;
         rvalid[j] = m < M;
         const uint32_t mm = rvalid[j] ? (uint32_t)m : 0u;          // M < 2^31 (checked on the host)
         if (d.gather != nullptr) {
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
         const int wrow0 = tap * d.Cout;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int n = bn0 + r0 + 32 * j;
+            const int n = bn0 + r0 + RSTEP * j;
             const bool ok = (n < d.Cout) & cvalid;
             pw[j] = d.w + (uint32_t)((wrow0 + (ok ? n : 0)) * d.Cin + cc);           // weights hold < 2^31 elements (host check)
             okbits |= (ok ? 1u : 0u) << (8 + j);
@@ -188,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
                 uint2 pc[3];
                 split3x4(v, pc);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.a[i][r0 + 32 * j][4 * kq]) = pc[i];
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.a[i][r0 + RSTEP * j][4 * kq]) = pc[i];
             } else {
-                *reinterpret_cast<float4*>(&sm.a[buf][r0 + 32 * j][4 * kq]) = v;
+                *reinterpret_cast<float4*>(&sm.a[buf][r0 + RSTEP * j][4 * kq]) = v;
             }
         }
 #pragma unroll
@@ -201,9 +207,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const gsdd_gemm_desc d, co
                 uint2 pc[3];
                 split3x4(v, pc);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.b[i][r0 + 32 * j][4 * kq]) = pc[i];
+                for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(&sx.b[i][r0 + RSTEP * j][4 * kq]) = pc[i];
             } else {
-                *reinterpret_cast<float4*>(&sm.b[buf][r0 + 32 * j][4 * kq]) = v;
+                *reinterpret_cast<float4*>(&sm.b[buf][r0 + RSTEP * j][4 * kq]) = v;
             }
         }
     };
@@ -404,13 +410,23 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
     GSDD_CHECK_ARG(d->gather != nullptr || (int64_t)d->N * d->Di * d->Hi * d->Wi < (1ll << 31), "more than 2^31 input rows");
     GSDD_CHECK_ARG((int64_t)d->ntaps * d->Cout * d->Cin < (1ll << 31), "more than 2^31 weight elements");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned gx = (unsigned)((M + BM - 1) / BM);
+    unsigned gx = (unsigned)((M + BM - 1) / BM);
     // bf16x3 on the matrix pipe when the contraction is long enough to pay for the splits; GSDD_GEMM_F32=1 forces the f32 MFMA
     static const bool force_f32 = getenv("GSDD_GEMM_F32") != nullptr;
     const bool x3 = !force_f32 && (int64_t)d->ntaps * d->Cin >= 64;
     if (d->Cout > 64) {
         const dim3 grid(gx, (d->Cout + 127) / 128);
-        if (x3) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, dim3(256), sizeof(GemmSmemX3<128>), st, *d, M);
+        const bool big = x3 && M >= 256 * 1024 / 2 && (int64_t)d->ntaps * d->Cin >= 1024;        // long contraction, many rows
+        if (big) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<128, true, 256, 512>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GemmSmemX3<128, 256>)));
+                attr_done = true;
+            }
+            const dim3 grid2((unsigned)((M + 255) / 256), (d->Cout + 127) / 128);
+            hipLaunchKernelGGL((gemm_kernel<128, true, 256, 512>), grid2, dim3(512), sizeof(GemmSmemX3<128, 256>), st, *d, M);
+        } else if (x3) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, dim3(256), sizeof(GemmSmemX3<128>), st, *d, M);
         else hipLaunchKernelGGL((gemm_kernel<128, false>), grid, dim3(256), sizeof(GemmSmem<128>), st, *d, M);
     } else {
         const dim3 grid(gx, 1);
