@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const gsdd_gemm_desc
 // thread -> patch map keeps every 16-lane group of the writes on distinct banks too).
 constexpr int CX_ROWS = 64, CX_PITCH = 72;
 typedef __bf16 cw_bf16x8 __attribute__((ext_vector_type(8)));
+template <int T>                             // T x T output tile (64 or 128)
 struct CwSmemX3 {
-    uint16_t t[2][3][64][CX_PITCH];          // [operand: dY | x][piece][column][slab row]
+    uint16_t t[2][3][T][CX_PITCH];           // [operand: dY | x][piece][column][slab row]
     int src[2][CX_ROWS];
     int dst[2][CX_ROWS];
 };
@@ -161,15 +162,19 @@ __device__ __forceinline__ uint32_t cw_cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const gsdd_gemm_desc d, const float* dY, int dy_pitch, float* dW,
-                                                               const int64_t M, int slabs, int ctiles) {
+// T = 64: 256 threads, a wave owns one 32x32 quadrant.  T = 128 (both channel counts >= 128): 512 threads, a wave owns two
+// quadrants; per MAC half the L2 traffic and half the split work of the 64x64 tile.
+template <int T>
+__global__ __launch_bounds__(4 * T, 128 / T) void conv_wgrad_x3_kernel(const gsdd_gemm_desc d, const float* dY, int dy_pitch,
+                                                                         float* dW, const int64_t M, int slabs, int ctiles) {
+    constexpr int NTH = 4 * T, HALF = NTH / 2, QC = T / 64;       // threads, threads per operand, c-quadrants per wave
     extern __shared__ __attribute__((aligned(16))) char cwx_raw[];
-    CwSmemX3& sm = *reinterpret_cast<CwSmemX3*>(cwx_raw);
+    CwSmemX3<T>& sm = *reinterpret_cast<CwSmemX3<T>*>(cwx_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = (blockIdx.y / ctiles) * 64, c0 = (blockIdx.y % ctiles) * 64;
+    const int n0 = (blockIdx.y / ctiles) * T, c0 = (blockIdx.y % ctiles) * T;
     const int tap = blockIdx.z;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave >> 1, wk = wave & 1;                      // n quadrant, first c quadrant = QC * wk
     int dt = 0, dh = 0, dw = 0;
     if (d.taps != nullptr) { dt = d.taps[3 * tap]; dh = d.taps[3 * tap + 1]; dw = d.taps[3 * tap + 2]; }
     const bool linear_rows = (d.oD == d.Do && d.oH == d.Ho && d.oW == d.Wo && d.osd == 1 && d.osh == 1 && d.osw == 1 &&
@@ -179,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const gsdd_gemm_d
     nsl = nsl < slabs ? nsl : slabs;
     if (nsl <= 0) return;
 
-    // staging patch of this thread: operand op, columns 4*cgrp..+3, slab rows 8*rgrp..+7
-    const int op = tid >> 7, t7 = tid & 127;
-    const int cgrp = 4 * ((t7 >> 4) & 3) + (t7 & 3), rgrp = 4 * (t7 >> 6) + ((t7 >> 2) & 3);
+    // staging patch of this thread: operand op, columns 4*cgrp..+3, slab rows 8*rgrp..+7 (bits: cgrp_lo 2, rgrp_lo 2, cgrp_hi, rgrp_hi)
+    const int op = tid / HALF, th = tid % HALF;
+    const int cgrp = 4 * ((th >> 4) % (T / 16)) + (th & 3), rgrp = 4 * (th / T) + ((th >> 2) & 3);
     const int c4 = 4 * cgrp;
     const bool col_ok = op == 0 ? (n0 + c4 < d.Cout) : (c0 + c4 < d.Cin);
     const int gcol = col_ok ? (op == 0 ? n0 + c4 : c0 + c4) : 0;
@@ -263,9 +268,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const gsdd_gemm_d
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[QC];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int qc = 0; qc < QC; ++qc)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[qc][i] = 0.f;
     decode(0);
     __syncthreads();
     issue(0);
@@ -277,31 +284,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const gsdd_gemm_d
         if (more) issue(sl + 1);
 #pragma unroll
         for (int ks = 0; ks < CX_ROWS / 16; ++ks) {
-            cw_bf16x8 yf[3], xf[3];
+            cw_bf16x8 yf[3], xf[QC][3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
-                union { uint4 u; cw_bf16x8 v; } a, b;
+                union { uint4 u; cw_bf16x8 v; } a;
                 a.u = *reinterpret_cast<const uint4*>(&sm.t[0][pc][wn * 32 + li][16 * ks + 8 * lh]);
-                b.u = *reinterpret_cast<const uint4*>(&sm.t[1][pc][wk * 32 + li][16 * ks + 8 * lh]);
-                yf[pc] = a.v; xf[pc] = b.v;
+                yf[pc] = a.v;
+#pragma unroll
+                for (int qc = 0; qc < QC; ++qc) {
+                    union { uint4 u; cw_bf16x8 v; } b;
+                    b.u = *reinterpret_cast<const uint4*>(&sm.t[1][pc][(QC * wk + qc) * 32 + li][16 * ks + 8 * lh]);
+                    xf[qc][pc] = b.v;
+                }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[2], xf[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[1], xf[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[1], xf[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[0], acc, 0, 0, 0);
+#pragma unroll
+            for (int qc = 0; qc < QC; ++qc) {
+                acc[qc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[2], xf[qc][0], acc[qc], 0, 0, 0);
+                acc[qc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[1], xf[qc][1], acc[qc], 0, 0, 0);
+                acc[qc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[qc][2], acc[qc], 0, 0, 0);
+                acc[qc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[1], xf[qc][0], acc[qc], 0, 0, 0);
+                acc[qc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[qc][1], acc[qc], 0, 0, 0);
+                acc[qc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[0], xf[qc][0], acc[qc], 0, 0, 0);
+            }
         }
         __syncthreads();                               // every wave is done with the tile
         if (more) stage();
     }
     float* out = dW + (int64_t)tap * d.Cout * d.Cin;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int c = c0 + wk * 32 + li;
-        if (n < d.Cout && c < d.Cin) atomicAdd(out + (int64_t)n * d.Cin + c, acc[r]);
-    }
+    for (int qc = 0; qc < QC; ++qc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int c = c0 + (QC * wk + qc) * 32 + li;
+            if (n < d.Cout && c < d.Cin) atomicAdd(out + (int64_t)n * d.Cin + c, acc[qc][r]);
+        }
 }
 
 // ------------------------------------------------------------------ BatchNorm(train) + ReLU backward on rows x[M][C]
@@ -454,22 +471,35 @@ extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_
     GSDD_CHECK_ARG(M < (1ll << 31), "more than 2^31 rows");
     GSDD_CHECK_ARG((int64_t)d->N * d->Di * d->Hi * d->Wi < (1ll << 31), "more than 2^31 input rows");
     GSDD_CHECK_ARG(d->oD > 0 && d->oH > 0 && d->oW > 0 && (int64_t)d->N * d->oD * d->oH * d->oW < (1ll << 31), "bad output dims");
-    const int ntiles = (d->Cout + 63) / 64, ctiles = (d->Cin + 63) / 64;
     static const bool force_f32 = getenv("GSDD_GEMM_F32") != nullptr;
+    const bool big = !force_f32 && d->Cout >= 128 && d->Cin >= 128;           // 128 x 128 output tiles on 512 threads
+    const int T = big ? 128 : 64;
+    const int ntiles = (d->Cout + T - 1) / T, ctiles = (d->Cin + T - 1) / T;
     const int rows_per_slab = force_f32 ? CW_ROWS : CX_ROWS;
-    // rows per block: enough blocks to fill the chip (>= ~2048), as few atomics per dW element as that allows
+    // rows per block: enough blocks to fill the chip (>= ~2048, half that for the big tile), as few atomics per dW element as
+    // that allows
     const int64_t nslabs = (M + rows_per_slab - 1) / rows_per_slab;
     const int64_t per_x = (int64_t)ntiles * ctiles * d->ntaps;
-    int64_t gx = (2048 + per_x - 1) / per_x;
+    int64_t gx = ((big ? 1024 : 2048) + per_x - 1) / per_x;
     gx = gx < 1 ? 1 : (gx > nslabs ? nslabs : gx);
     int slabs = (int)((nslabs + gx - 1) / gx);
     slabs = slabs < 8 ? (nslabs < 8 ? (int)nslabs : 8) : (slabs > 128 ? 128 : slabs);
     const dim3 grid((unsigned)((nslabs + slabs - 1) / slabs), ntiles * ctiles, d->ntaps);
-    if (force_f32)
+    if (force_f32) {
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), sizeof(CwSmem), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
-    else
-        hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(256), sizeof(CwSmemX3), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs,
-                           ctiles);
+    } else if (big) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(CwSmemX3<128>)));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(512), sizeof(CwSmemX3<128>), (hipStream_t)stream, *d, dY, dy_pitch, dW, M,
+                           slabs, ctiles);
+    } else {
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, dim3(256), sizeof(CwSmemX3<64>), (hipStream_t)stream, *d, dY, dy_pitch, dW, M,
+                           slabs, ctiles);
+    }
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -52,6 +52,9 @@ def case(G, golden, name):
     if name == "ds444":       # every transposed conv strides time too (the last one takes the merged-W gradient path with s_t = 2)
         cfg = dict(embedding_dim=8, n_codes=16, n_hiddens=16, n_res_layers=1, downsample=[4, 4, 4], sequence_length=8, resolution=16)
         xshape, nperm = (2, 3, 8, 16, 16), 2 * 2 * 4 * 4
+    elif name == "c128":      # 128 channels: the 128x128 weight-gradient tiles and the 128-wide GEMM tiles
+        cfg = dict(embedding_dim=16, n_codes=32, n_hiddens=128, n_res_layers=1, downsample=[2, 4, 4], sequence_length=4, resolution=16)
+        xshape, nperm = (2, 3, 4, 16, 16), 2 * 2 * 4 * 4
     else:                     # wider net: channel counts that are not multiples of the 64-wide tiles, stride-1 time axis in layer 2
         cfg = dict(embedding_dim=12, n_codes=40, n_hiddens=48, n_res_layers=2, downsample=[2, 4, 4], sequence_length=4, resolution=16)
         xshape, nperm = (3, 3, 4, 16, 16), 3 * 2 * 4 * 4
@@ -88,7 +91,7 @@ def compare(got, want, tol=2e-3):
     print("worst relative gradient error:", worst)
 
 
-@pytest.mark.parametrize("name", ["train_ds188", "ds244", "wide", "ds444"])
+@pytest.mark.parametrize("name", ["train_ds188", "ds244", "wide", "ds444", "c128"])
 def test_vqvae_gradients_match_autograd_of_oracle(G, golden, name):
     from gsdd_amd.vqvae_trainer import VQVAETrainer
     x, sd, cfg, perm = case(G, golden, name)
