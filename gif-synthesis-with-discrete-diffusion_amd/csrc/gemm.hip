@@ -71,31 +71,34 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 
 // Block tile BMt x BN, NTH threads = NTH/64 waves laid out (BMt/64) x 2, each wave 64 x BN/2.  BMt = 128 (256 threads, two
 // blocks per CU) everywhere except the big bf16x3 convolutions, which take BMt = 256 (512 threads, one block per CU): the weight
-// tile is staged once per 256 rows, a quarter less L2 traffic and staging work per MAC.
+// tile is staged once per 256 rows, a quarter less L2 traffic and staging work per MAC (measured: +6 %; the transposed choice,
+// 128 x 256 with the activation tile staged once per 256 output channels, instantiates too but runs 4 % slower than that).
 template <int BN, bool X3, int BMt = BM, int NTH = 256>
 __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_desc d, const int64_t M) {
-    constexpr int NT = BN / 64;          // 32-wide n tiles per wave
+    constexpr int WNW = BN >= 128 ? 64 : 32;   // columns per wave
+    constexpr int NT = WNW / 32;         // 32-wide n tiles per wave
+    constexpr int WN = BN / WNW;         // waves along n (the others stack along m, 64 rows each)
     constexpr int RSTEP = NTH / 8;       // rows staged per pass of the block's threads (8 threads per 32-k row)
     constexpr int RA = BMt / RSTEP;      // activation rows staged per thread
     constexpr int BJ = BN / RSTEP;       // weight rows staged per thread
-    static_assert(RA == 4, "the staging code below is written for 4 activation rows per thread");
+    static_assert((NTH / 64) / WN * 64 == BMt, "wave grid must cover the tile");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     GemmSmem<BN, BMt>& sm = *reinterpret_cast<GemmSmem<BN, BMt>*>(smem_raw);
     GemmSmemX3<BN, BMt>& sx = *reinterpret_cast<GemmSmemX3<BN, BMt>*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int64_t bm0 = (int64_t)blockIdx.x * BMt;
     const int bn0 = blockIdx.y * BN;
     const int kq = tid & 7, r0 = tid >> 3;
 
     // ---- per-thread staged rows of the activation operand (row index and tap-free coordinates, all 32-bit)
-    int ti0[4], hi0[4], wi0[4], rbase[4];
-    bool rvalid[4];
-    float mu[4], rs[4];
-    int64_t sel[4];
+    int ti0[RA], hi0[RA], wi0[RA], rbase[RA];
+    bool rvalid[RA];
+    float mu[RA], rs[RA];
+    int64_t sel[RA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RA; ++j) {
         const int64_t m = bm0 + r0 + RSTEP * j;
         rvalid[j] = m < M;
         const uint32_t mm = rvalid[j] ? (uint32_t)m : 0u;          // M < 2^31 (checked on the host)
@@ -126,13 +129,13 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
     // Global loads of chunk i+1 are issued before the MFMAs of chunk i and consumed after them.  They are branch-free
     // (out-of-range rows / channels read a clamped, valid address and are zeroed when staged into LDS): a load under an
     // exec-masked branch makes the compiler wait for it on the spot, which serialises memory latency with the MFMAs.
-    float4 ra[4], rb[BJ], ps, pb;
+    float4 ra[RA], rb[BJ], ps, pb;
     unsigned okbits = 0;
     int cc = 0;
     // Chunks are requested in order, so (tap, channel chunk) is a running counter, and everything that depends on the tap alone
     // (source row, bounds test) is computed once per tap and re-used by its channel chunks.
     int ld_tap = 0, ld_cq = 0;
-    const float* prow[4];
+    const float* prow[RA];
     unsigned rowok = 0;
     auto load_chunk = [&](int /*chunk: always the next one*/) {
         const int tap = ld_tap;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
             const int tapoff = (dt * d.Hi + dh) * d.Wi + dw;
             rowok = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < RA; ++j) {
                 const int ti = ti0[j] + dt, hi = hi0[j] + dh, wi = wi0[j] + dw;
                 const bool ok = rvalid[j] & ((unsigned)ti < (unsigned)d.Di) & ((unsigned)hi < (unsigned)d.Hi) &
                                 ((unsigned)wi < (unsigned)d.Wi);
@@ -158,10 +161,10 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
         ps = *reinterpret_cast<const float4*>(pro_s + cc);
         pb = *reinterpret_cast<const float4*>(pro_b + cc);
         okbits = cvalid ? rowok : 0u;
-        const float* pa[4];
+        const float* pa[RA];
         const float* pw[BJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pa[j] = prow[j] + cc;
+        for (int j = 0; j < RA; ++j) pa[j] = prow[j] + cc;
         const int wrow0 = tap * d.Cout;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
@@ -171,13 +174,13 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
             okbits |= (ok ? 1u : 0u) << (8 + j);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j]);
+        for (int j = 0; j < RA; ++j) ra[j] = *reinterpret_cast<const float4*>(pa[j]);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const float4*>(pw[j]);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RA; ++j) {
             float4 v = ra[j];
             if (has_pro) {
                 v.x = fmaxf(fmaf(v.x, ps.x, pb.x), 0.f); v.y = fmaxf(fmaf(v.y, ps.y, pb.y), 0.f);
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
                         af[mt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.a[i][wm * 64 + mt * 32 + li][16 * ks + 8 * lh]));
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        bf[nt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.b[i][wn * (BN / 2) + nt * 32 + li][16 * ks + 8 * lh]));
+                        bf[nt][i] = as_bf8(*reinterpret_cast<const uint4*>(&sx.b[i][wn * WNW + nt * 32 + li][16 * ks + 8 * lh]));
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
                 af[mt] = *reinterpret_cast<const float4*>(&sm.a[buf][wm * 64 + mt * 32 + li][16 * lh + 4 * q]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                bf[nt] = *reinterpret_cast<const float4*>(&sm.b[buf][wn * (BN / 2) + nt * 32 + li][16 * lh + 4 * q]);
+                bf[nt] = *reinterpret_cast<const float4*>(&sm.b[buf][wn * WNW + nt * 32 + li][16 * lh + 4 * q]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(NTH, 512 / NTH) void gemm_kernel(const gsdd_gemm_de
     float es[NT], eh[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        ncol[nt] = bn0 + wn * (BN / 2) + nt * 32 + li;
+        ncol[nt] = bn0 + wn * WNW + nt * 32 + li;
         nok[nt] = ncol[nt] < d.Cout;
         es[nt] = (d.epi_scale != nullptr && nok[nt]) ? d.epi_scale[ncol[nt]] : 1.f;
         eh[nt] = (d.epi_shift != nullptr && nok[nt]) ? d.epi_shift[ncol[nt]] : 0.f;
