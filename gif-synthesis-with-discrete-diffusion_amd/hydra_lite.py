@@ -107,29 +107,39 @@ def _compose_file(config_dir, rel, group_dir, group_choice):
 _INTERP = re.compile(r"\$\{([^}]+)\}")
 
 
-def _resolve(root, node):
+def _resolve(root, node, where=()):
+    """``where`` is the key path of the container that holds ``node`` (for ``${.sibling}`` / ``${..uncle}``)."""
     if isinstance(node, dict):
         for k in list(node):
-            node[k] = _resolve(root, node[k])
+            node[k] = _resolve(root, node[k], where + (k,))
         return node
     if isinstance(node, list):
-        return [_resolve(root, v) for v in node]
+        return [_resolve(root, v, where) for v in node]
     if isinstance(node, str):
+        holder = where[:-1]                            # a leaf's own key is the last element
         m = _INTERP.fullmatch(node)
         if m:
-            return _resolve(root, _lookup(root, m.group(1)))
-        return _INTERP.sub(lambda mm: str(_resolve(root, _lookup(root, mm.group(1)))), node)
+            tgt, at = _lookup(root, m.group(1), holder)
+            return _resolve(root, tgt, at)
+        return _INTERP.sub(lambda mm: str(_resolve(root, *_lookup(root, mm.group(1), holder))), node)
     return node
 
 
-def _lookup(root, dotted):
+def _lookup(root, dotted, holder=()):
+    """Value of an interpolation key and the key path it was found at."""
     if dotted.startswith("oc.env:"):
         name, _, default = dotted[7:].partition(",")
-        return os.environ.get(name, default)
+        return os.environ.get(name, default), ()
+    base = ()
+    if dotted.startswith("."):
+        ups = len(dotted) - len(dotted.lstrip("."))
+        dotted = dotted[ups:]
+        base = holder[:len(holder) - (ups - 1)] if ups > 1 else holder
+    path = base + tuple(dotted.split("."))
     cur = root
-    for k in dotted.split("."):
+    for k in path:
         cur = cur[k]
-    return cur
+    return cur, path
 
 
 def compose(config_dir, config_name, overrides=()):
@@ -145,7 +155,7 @@ def compose(config_dir, config_name, overrides=()):
     cfg = _compose_file(config_dir, config_name, "", group_choice)
     for k, v in sets:
         _set_path(cfg, k, v)
-    return _wrap(_resolve(cfg, cfg))
+    return _wrap(_resolve(cfg, cfg, ()))
 
 
 def get_class(path):
