@@ -55,8 +55,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        // one widening multiply per product (v_mad_u64_u32 issues at the rate of a single v_mul_lo/hi_u32)
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
@@ -69,8 +71,10 @@ __device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint32_t stream
     const uint64_t ctr = row * (uint64_t)kp4 + col4;
     const uint4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), stream_id, 0u, (uint32_t)seed,
                                   (uint32_t)(seed >> 32));
-    constexpr float S = 1.0f / 16777216.0f;
-    return make_float4((float)(r.x >> 8) * S, (float)(r.y >> 8) * S, (float)(r.z >> 8) * S, (float)(r.w >> 8) * S);
+    // top 24 bits / 2^24, written as (r with its low byte cleared) / 2^32: the same value, the mask issues at full rate
+    constexpr float S = 1.0f / 4294967296.0f;
+    constexpr uint32_t M = 0xFFFFFF00u;
+    return make_float4((float)(r.x & M) * S, (float)(r.y & M) * S, (float)(r.z & M) * S, (float)(r.w & M) * S);
 }
 
 }  // namespace gsdd

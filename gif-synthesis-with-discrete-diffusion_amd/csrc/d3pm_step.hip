@@ -12,9 +12,42 @@ namespace gsdd {
 
 constexpr float LOG_ZERO = -69.07755278982137f;  // log(1e-30)
 
-__device__ __forceinline__ float lae(float a, float b) {  // reference log_add_exp (:32-34)
+// expf / logf restricted to the argument ranges this file feeds them.  Both run the device library's own
+// arithmetic (two-constant log2(e) / ln 2 products around v_exp_f32 / v_log_f32, same constants, same order), so
+// results are bit-identical to expf / logf on those ranges; what is dropped is the library's range plumbing
+// (two compare+select pairs per expf, denormal pre-scaling and the inf/nan select per logf), which costs more issue
+// slots than the arithmetic itself (tools/rate_probe6.hip: compares and selects issue at half the f32 add/mul rate).
+//   exp_le0(x): x <= 0 (or -inf).  The lower clamp stands in for the library's "x < -103.28 -> 0" select:
+//               exp(-104) < 2^-150 rounds to 0 in v_ldexp_f32, and it keeps a -inf / absurdly negative
+//               argument away from the hi/lo product.
+//   log_norm(x): x finite and >= 2^-126 (here always >= 1e-30).
+//               CLAMP = false where the argument is known to be finite and of moderate size (differences of clamped
+//               log-probabilities and schedule constants): the clamp is one more half-rate instruction.
+template <bool CLAMP = true>
+__device__ __forceinline__ float exp_le0(float x) {
+    const float L2E_HI = __builtin_bit_cast(float, 0x3fb8aa3bu), L2E_LO = __builtin_bit_cast(float, 0x32a5705fu);
+    if (CLAMP) x = fmaxf(x, -104.f);
+    const float ph = x * L2E_HI;
+    float pl = fmaf(x, L2E_HI, -ph);
+    const float e = rintf(ph);
+    pl = fmaf(x, L2E_LO, pl);
+    const float a = (ph - e) + pl;
+    return ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
+__device__ __forceinline__ float log_norm(float x) {
+    const float LN2_HI = __builtin_bit_cast(float, 0x3f317217u), LN2_LO = __builtin_bit_cast(float, 0x3377d1cfu);
+    const float r = __builtin_amdgcn_logf(x);
+    const float ph = r * LN2_HI;
+    float pl = fmaf(r, LN2_HI, -ph);
+    pl = fmaf(r, LN2_LO, pl);
+    return ph + pl;
+}
+
+// reference log_add_exp (:32-34): m + log(exp(a - m) + exp(b - m)), m = max(a, b).  One of the two exponentials is
+// exp(0) = 1 exactly and the other one's argument is -|a - b| exactly, so a single exp gives the same bits.
+__device__ __forceinline__ float lae(float a, float b) {
     const float m = fmaxf(a, b);
-    return m + logf(expf(a - m) + expf(b - m));
+    return m + log_norm(1.f + exp_le0(-fabsf(a - b)));   // clamped: a schedule constant may be log(0) = -inf (t - 1 wrap)
 }
 __device__ __forceinline__ float clamp70(float v) { return fminf(fmaxf(v, -70.f), 0.f); }
 
@@ -48,7 +81,7 @@ __device__ __forceinline__ void log_softmax_clamp(float (&x)[J][4]) {
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) se += (double)expf(x[j][e] - mx);
+        for (int e = 0; e < 4; ++e) se += (double)exp_le0(x[j][e] - mx);
     se = wave_sum(se);
     const double lse = (double)mx + log(se);
 #pragma unroll
@@ -57,7 +90,8 @@ __device__ __forceinline__ void log_softmax_clamp(float (&x)[J][4]) {
         for (int e = 0; e < 4; ++e) x[j][e] = clamp70((float)((double)x[j][e] - lse));
 }
 
-template <int J>
+// CLAMP = false: every slot holds a finite, bounded value (FULL rows of clamped log-probabilities)
+template <int J, bool CLAMP = true>
 __device__ __forceinline__ float wave_logsumexp(const float (&x)[J][4], float extra, bool has_extra) {
     float mx = has_extra ? extra : -INFINITY;
 #pragma unroll
@@ -69,14 +103,14 @@ __device__ __forceinline__ float wave_logsumexp(const float (&x)[J][4], float ex
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) se += expf(x[j][e] - mx);
+        for (int e = 0; e < 4; ++e) se += exp_le0<CLAMP>(x[j][e] - mx);
     se = wave_sum(se);
-    if (has_extra) se += expf(extra - mx);
+    if (has_extra) se += exp_le0(extra - mx);
     return mx + logf(se);
 }
 
-__device__ __forceinline__ float gumbel(float u) {  // log_sample_categorical (:355-356)
-    return -logf(-logf(u + 1e-30f) + 1e-30f);
+__device__ __forceinline__ float gumbel(float u) {  // log_sample_categorical (:355-356); u in [0, 1)
+    return -log_norm(-log_norm(u + 1e-30f) + 1e-30f);
 }
 
 // arg-max of (val, idx) over the wave, first index wins ties (torch.argmax)
@@ -90,10 +124,15 @@ __device__ __forceinline__ int wave_argmax(float v, int idx) {
     return idx;
 }
 
-template <int J>
-__global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedPtrs sp) {
+// FULL: K == 256 * J, every register slot holds a class (no validity selects).  DBG: the posterior / x0 test hooks
+// are compiled in; the production instantiation has none, so the unrolled class loops are single basic blocks.
+// Everything that depends only on the position (token, timestep, schedule row, which register slot holds class x_t)
+// is wave-uniform: the wave index goes through readfirstlane so that the compiler keeps it in SGPRs, and the
+// "k == x_t" special case becomes a scalar branch on j plus one lane compare instead of a compare+select per class.
+template <int J, bool FULL, bool DBG>
+__global__ __launch_bounds__(256, 3) void d3pm_step_kernel(gsdd_step_desc d, SchedPtrs sp) {
     const int lane = threadIdx.x & 63;
-    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t pos = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (pos >= (int64_t)d.B * d.L) return;
     const int b = (int)(pos / d.L), l = (int)(pos % d.L);
     const int K = d.K;
@@ -105,7 +144,7 @@ __global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedP
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int k = 4 * lane + 256 * j;
-            if (k < K) {
+            if (FULL || k < K) {
                 const float4 v = *reinterpret_cast<const float4*>(row + k);
                 x0[j][0] = v.x; x0[j][1] = v.y; x0[j][2] = v.z; x0[j][3] = v.w;
             } else {
@@ -120,7 +159,7 @@ __global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedP
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int k = 4 * lane + 256 * j;
-            if (k < K) {
+            if (FULL || k < K) {
                 const float4 v = *reinterpret_cast<const float4*>(row + k);
                 xu[j][0] = v.x; xu[j][1] = v.y; xu[j][2] = v.z; xu[j][3] = v.w;
             } else {
@@ -130,7 +169,7 @@ __global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedP
         log_softmax_clamp<J>(xu);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const bool valid = (4 * lane + 256 * j) < K;
+            const bool valid = FULL || (4 * lane + 256 * j) < K;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float diff = x0[j][e] - xu[j][e];
@@ -138,15 +177,15 @@ __global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedP
                 x0[j][e] = valid ? (xu[j][e] + sc) : NEG;
             }
         }
-        const float lse = wave_logsumexp<J>(x0, 0.f, false);
+        const float lse = wave_logsumexp<J, !FULL>(x0, 0.f, false);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const bool valid = (4 * lane + 256 * j) < K;
+            const bool valid = FULL || (4 * lane + 256 * j) < K;
 #pragma unroll
             for (int e = 0; e < 4; ++e) x0[j][e] = valid ? clamp70(x0[j][e] - lse) : NEG;
         }
     }
-    if (d.x0_dbg != nullptr) {
+    if (DBG && d.x0_dbg != nullptr) {
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -160,39 +199,53 @@ __global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedP
     // ---- q_posterior (:251-283)
     const int64_t t = d.t_dev[b];
     const StepSched s = load_sched(sp.p, t, d.T);
-    const int64_t xt = d.tok_in[pos];
+    const int xt = (int)d.tok_in[pos];
     const bool masked = (xt == K);
-    const float qt_hit = lae(0.f + s.lca, s.lcb), qt_miss = lae(LOG_ZERO + s.lca, s.lcb);
-    const float q1_hit = lae(0.f + s.la, s.lb), q1_miss = lae(LOG_ZERO + s.la, s.lb);
+    // class x_t sits in register slot [xj][xe] of lane xl (for x_t = [MASK] that slot does not exist or is invalid,
+    // and the "hit" constants equal the "miss" ones, so no case distinction is needed below)
+    const int xj = xt >> 8, xl = (xt >> 2) & 63, xe = xt & 3;
+    const bool mine = (lane == xl);
+    const float qt_miss = masked ? s.lcc : lae(LOG_ZERO + s.lca, s.lcb);
+    const float qt_hit = masked ? s.lcc : lae(0.f + s.lca, s.lcb);
+    const float q1_miss = masked ? s.lc : lae(LOG_ZERO + s.la, s.lb);
+    const float q1_hit = masked ? s.lc : lae(0.f + s.la, s.lb);
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+    for (int j = 0; j < J; ++j) {
+        const bool valid = FULL || (4 * lane + 256 * j) < K;
+        if (j == xj) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-            x0[j][e] = (k < K) ? (x0[j][e] - log_qt) : NEG;
+            for (int e = 0; e < 4; ++e) x0[j][e] = valid ? (x0[j][e] - ((mine && e == xe) ? qt_hit : qt_miss)) : NEG;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x0[j][e] = valid ? (x0[j][e] - qt_miss) : NEG;
         }
-    const float S = wave_logsumexp<J>(x0, LOG_ZERO, true);
+    }
+    const float S = wave_logsumexp<J, !FULL>(x0, LOG_ZERO, true);
     float best = NEG;
     int best_k = 0;
     const uint32_t kp4 = (uint32_t)((K + 1 + 3) / 4);
     const uint32_t stream_id = (uint32_t)d.stream_dev[0];
     const uint64_t grow = (uint64_t)(d.row0 + pos);
+    auto draw = [&](int j, int e, float log_q1, float u) {
+        const int k = 4 * lane + 256 * j + e;
+        const float qn = x0[j][e] - S;
+        const float o = clamp70(lae(qn + s.pca, s.pcb) + log_q1 + S);
+        if (DBG && d.post_dbg != nullptr) d.post_dbg[((int64_t)b * (K + 1) + k) * d.L + l] = o;
+        const float v = gumbel(u) + o;
+        if (v > best) { best = v; best_k = k; }
+    };
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k0 = 4 * lane + 256 * j;
-        if (k0 < K) {
+        if (FULL || k0 < K) {
             const float4 u4 = philox_uniform4(d.seed, stream_id, grow, kp4, (uint32_t)(k0 >> 2));
             const float u[4] = {u4.x, u4.y, u4.z, u4.w};
+            if (j == xj) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = k0 + e;
-                const float qn = x0[j][e] - S;
-                const float log_q1 = masked ? s.lc : (k == xt ? q1_hit : q1_miss);
-                const float o = clamp70(lae(qn + s.pca, s.pcb) + log_q1 + S);
-                if (d.post_dbg != nullptr) d.post_dbg[((int64_t)b * (K + 1) + k) * d.L + l] = o;
-                const float v = gumbel(u[e]) + o;
-                if (v > best) { best = v; best_k = k; }
+                for (int e = 0; e < 4; ++e) draw(j, e, (mine && e == xe) ? q1_hit : q1_miss, u[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) draw(j, e, q1_miss, u[e]);
             }
         }
     }
@@ -201,7 +254,7 @@ __global__ __launch_bounds__(256) void d3pm_step_kernel(gsdd_step_desc d, SchedP
         const float qn = LOG_ZERO - S;
         const float log_q1 = masked ? 0.f : LOG_ZERO;
         const float o = clamp70(lae(qn + s.p1mcc, s.pcc) + log_q1 + S);
-        if (d.post_dbg != nullptr) d.post_dbg[((int64_t)b * (K + 1) + K) * d.L + l] = o;
+        if (DBG && d.post_dbg != nullptr) d.post_dbg[((int64_t)b * (K + 1) + K) * d.L + l] = o;
         const float v = gumbel(u4.x) + o;
         if (v > best) { best = v; best_k = K; }
     }
@@ -643,12 +696,22 @@ extern "C" int gsdd_d3pm_step(const gsdd_step_desc* d, void* stream) {
     const dim3 grid((unsigned)((npos + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int J = (d->K + 255) / 256;
-    if (J <= 1) hipLaunchKernelGGL(d3pm_step_kernel<1>, grid, block, 0, st, *d, sp);
-    else if (J <= 2) hipLaunchKernelGGL(d3pm_step_kernel<2>, grid, block, 0, st, *d, sp);
-    else if (J <= 4) hipLaunchKernelGGL(d3pm_step_kernel<4>, grid, block, 0, st, *d, sp);
-    else if (J <= 8) hipLaunchKernelGGL(d3pm_step_kernel<8>, grid, block, 0, st, *d, sp);
-    else if (J <= 16) hipLaunchKernelGGL(d3pm_step_kernel<16>, grid, block, 0, st, *d, sp);
-    else hipLaunchKernelGGL(d3pm_step_kernel<32>, grid, block, 0, st, *d, sp);
+    const bool dbg = d->post_dbg != nullptr || d->x0_dbg != nullptr;
+#define GSDD_STEP_LAUNCH(JJ)                                                                                         \
+    do {                                                                                                             \
+        const bool full = d->K == 256 * (JJ);                                                                        \
+        if (full && !dbg) hipLaunchKernelGGL((d3pm_step_kernel<JJ, true, false>), grid, block, 0, st, *d, sp);      \
+        else if (full) hipLaunchKernelGGL((d3pm_step_kernel<JJ, true, true>), grid, block, 0, st, *d, sp);          \
+        else if (!dbg) hipLaunchKernelGGL((d3pm_step_kernel<JJ, false, false>), grid, block, 0, st, *d, sp);        \
+        else hipLaunchKernelGGL((d3pm_step_kernel<JJ, false, true>), grid, block, 0, st, *d, sp);                   \
+    } while (0)
+    if (J <= 1) GSDD_STEP_LAUNCH(1);
+    else if (J <= 2) GSDD_STEP_LAUNCH(2);
+    else if (J <= 4) GSDD_STEP_LAUNCH(4);
+    else if (J <= 8) GSDD_STEP_LAUNCH(8);
+    else if (J <= 16) GSDD_STEP_LAUNCH(16);
+    else GSDD_STEP_LAUNCH(32);
+#undef GSDD_STEP_LAUNCH
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -200,6 +200,42 @@ def test_step_kernel_alone_matches_oracle(G, golden):
     torch.testing.assert_close(post.cpu(), want, atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("K", [4096, 768])
+def test_step_kernel_full_width_matches_oracle(G, K):
+    """K = 4096 takes the kernel instantiation without validity selects and without test hooks (the one the sampler
+    runs at the benchmark size); K = 768 a partially filled register grid.  Same inputs through the hooked
+    instantiation (posterior values) and through the oracle: tokens must agree bit for bit, guided and unguided,
+    with masked and unmasked x_t and t = 0 in the batch."""
+    from oracle import d3pm as od
+    from gsdd_amd.d3pm import SCHED_ORDER
+    B, L, T, seed, stream = 3, 8, 100, 4321, 7
+    g = torch.Generator().manual_seed(K)
+    lc = torch.randn(B, K, L, generator=g) * 3.0
+    lu = lc + torch.randn(B, K, L, generator=g)
+    xt = torch.randint(0, K, (B, L), generator=g)
+    xt[:, ::3] = K                                             # [MASK]
+    t = torch.tensor([57, 0, 99])
+    sd = od.schedule_buffers(T, K)
+    sched = [dev(sd[n]) for n in SCHED_ORDER]
+    rows = lambda x: dev(np.ascontiguousarray(x.numpy().transpose(0, 2, 1))).view(B * L, K)
+    sid = torch.tensor([stream], dtype=torch.int64, device="cuda")
+    log_xt = od.index_to_log_onehot(xt, K + 1)
+    for guided in (True, False):
+        rec = od.cf_mix(od.predict_start_from_logits(lc)[:, :-1], od.predict_start_from_logits(lu)[:, :-1], 2.0) \
+            if guided else od.predict_start_from_logits(lc)
+        want_post = od.q_posterior(rec, log_xt, t, sd)
+        want_tok = od.gumbel_argmax(want_post, seed, stream)
+        post = torch.empty((B, K + 1, L), device="cuda")
+        hooked, plain = torch.empty_like(xt).cuda(), torch.empty_like(xt).cuda()
+        args = (rows(lc), rows(lu) if guided else None, dev(xt))
+        kw = dict(K=K, T=T, guidance=2.0, seed=seed)
+        G.ops.d3pm_step(*args, hooked, sched, dev(t), sid, post_dbg=post, **kw)
+        G.ops.d3pm_step(*args, plain, sched, dev(t), sid, **kw)
+        torch.testing.assert_close(post.cpu(), want_post, atol=2e-5, rtol=0)
+        assert np.array_equal(hooked.cpu().numpy(), want_tok.numpy())
+        assert np.array_equal(plain.cpu().numpy(), want_tok.numpy())
+
+
 def test_full_reverse_loop_tokens_bit_exact(G, golden):
     sd, a, cfg = golden("d3pm_L64")
     dm = build_d3pm(G, sd, cfg)
