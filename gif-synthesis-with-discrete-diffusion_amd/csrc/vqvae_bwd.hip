@@ -324,7 +324,7 @@ __global__ __launch_bounds__(4 * T, 128 / T) void conv_wgrad_x3_kernel(const gsd
 // ------------------------------------------------------------------ BatchNorm(train) + ReLU backward on rows x[M][C]
 //   a = relu(y), y = gamma*xhat + beta, xhat = (x - mean)*rstd ; given da:
 //   dy = da*[y>0] ; dbeta = sum dy ; dgamma = sum dy*xhat ; dx = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat))
-constexpr int BB_ROWS = 512;
+constexpr int BB_ROWS = 64;        // >= 1024 stage-1 blocks at the training shapes
 __global__ __launch_bounds__(256) void bn_relu_bwd_partial_kernel(const float* da, const float* x, const float* mean_rstd,
                                                                   const float* gamma, const float* beta, int64_t M, int C,
                                                                   double* part) {
@@ -344,11 +344,19 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_partial_kernel(const float* d
         part[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
     }
 }
-__global__ void bn_relu_bwd_reduce_kernel(const double* part, int nblk, int C, float* dgamma, float* dbeta, float* sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one 256-thread block per channel
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const double* part, int nblk, int C, float* dgamma, float* dbeta,
+                                                                 float* sums) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
+    for (int b = threadIdx.x; b < nblk; b += 256) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     dbeta[c] += (float)s1;
     dgamma[c] += (float)s2;
     sums[2 * c] = (float)s1;
@@ -520,7 +528,7 @@ extern "C" int gsdd_bn_relu_bwd(const float* da, const float* x, int64_t M, int 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(nblk), dim3(256), 0, st, da, x, mean_rstd, gamma, beta, M, C, part);
     GSDD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nblk, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(C), dim3(256), 0, st, part, nblk, C, dgamma, dbeta, sums);
     GSDD_CHECK_LAUNCH();
     const int64_t n = M * (C / 4);
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, da, x, mean_rstd, gamma, beta,

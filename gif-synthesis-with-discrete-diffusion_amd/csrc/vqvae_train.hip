@@ -5,7 +5,7 @@
 
 namespace gsdd {
 
-constexpr int ST_ROWS = 512;      // rows per stage-1 block
+constexpr int ST_ROWS = 64;       // rows per stage-1 block: >= 1024 blocks at the training shapes (one thread per channel, serial over rows)
 
 // stage 1: per (row slab, channel) partial sum and sum of squares
 __global__ __launch_bounds__(256) void channel_stats_partial_kernel(const float* x, int64_t M, int C, double* part) {
@@ -25,16 +25,29 @@ __global__ __launch_bounds__(256) void channel_stats_partial_kernel(const float*
 
 // stage 2 + BatchNorm bookkeeping: batch mean / biased variance -> folded (scale, shift); running stats updated with
 // the unbiased variance and `momentum` exactly like torch (running = (1-m) running + m stat)
-__global__ void bn_train_finalize_kernel(const double* part, int nblk, int64_t M, int C, const float* weight,
-                                         const float* bias, float eps, float momentum, float* running_mean,
-                                         float* running_var, float* scale, float* shift, float* mean_rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// block sum of a pair of doubles over 256 threads (result valid in thread 0)
+__device__ __forceinline__ void block_sum2(double& s, double& q) {
+    __shared__ double red[2][4];
+    s = wave_sum(s); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// stage 2 + BatchNorm bookkeeping, one 256-thread block per channel: batch mean / biased variance -> folded (scale, shift);
+// running stats updated with the unbiased variance and `momentum` exactly like torch (running = (1-m) running + m stat)
+__global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* part, int nblk, int64_t M, int C, const float* weight,
+                                                                const float* bias, float eps, float momentum, float* running_mean,
+                                                                float* running_var, float* scale, float* shift, float* mean_rstd) {
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 256) {
         s += part[((int64_t)b * C + c) * 2 + 0];
         q += part[((int64_t)b * C + c) * 2 + 1];
     }
+    block_sum2(s, q);
+    if (threadIdx.x != 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     var = var < 0.0 ? 0.0 : var;
@@ -141,7 +154,7 @@ extern "C" int gsdd_bn_train(const float* x, int64_t M, int C, const float* weig
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(channel_stats_partial_kernel, dim3(nblk), dim3(256), 0, st, x, M, C, (double*)workspace);
     GSDD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const double*)workspace, nblk, M, C,
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(C), dim3(256), 0, st, (const double*)workspace, nblk, M, C,
                        weight, bias, eps, momentum, running_mean, running_var, scale, shift, mean_rstd);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
