@@ -77,4 +77,10 @@ __device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint32_t stream
     return make_float4((float)(r.x & M) * S, (float)(r.y & M) * S, (float)(r.z & M) * S, (float)(r.w & M) * S);
 }
 
+// axial_attention_mfma.hip: register-resident MFMA kernels for 16-position lines; false = shape not covered
+bool axial_attention_mfma_launch(const float* qkv, int N, int T, int H, int W, int C, int n_head, int axis, float* out,
+                                 hipStream_t st);
+bool axial_attention_bwd_mfma_launch(const float* qkv, const float* datt, int N, int T, int H, int W, int C, int n_head, int axis,
+                                     float* dqkv, hipStream_t st);
+
 }  // namespace gsdd

@@ -279,7 +279,12 @@ extern "C" int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W
     hipStream_t st = (hipStream_t)stream;
     const int axes_len[3] = {W, H, T};
     const int64_t pos = (int64_t)N * T * H * W;
+    static const bool force_valu = getenv("GSDD_AXIAL_VALU") != nullptr;
     for (int axis = 0; axis < 3; ++axis) {
+        if (!force_valu && axial_attention_mfma_launch(qkv, N, T, H, W, C, n_head, axis, out, st)) {
+            GSDD_CHECK_LAUNCH();
+            continue;
+        }
         const int S = axes_len[axis];
         const size_t lds = (size_t)(3 * S * (d + 1) + S * S) * sizeof(float);
         GSDD_CHECK_ARG(lds <= 64 * 1024, "line does not fit LDS");
