@@ -433,7 +433,19 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
         else hipLaunchKernelGGL((gemm_kernel<128, false>), grid, dim3(256), sizeof(GemmSmem<128>), st, *d, M);
     } else {
         const dim3 grid(gx, 1);
-        if (x3) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, dim3(256), sizeof(GemmSmemX3<64>), st, *d, M);
+        // few output channels over many rows and a long contraction (the Cout = 3 transposed conv): a 256 x 32 tile spends half
+        // the matrix-pipe time of the 128 x 64 one on padding columns
+        const bool narrow = x3 && d->Cout <= 32 && M >= 256 * 1024 / 2 && (int64_t)d->ntaps * d->Cin >= 1024;
+        if (narrow) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<32, true, 256, 256>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GemmSmemX3<32, 256>)));
+                attr_done = true;
+            }
+            const dim3 grid2((unsigned)((M + 255) / 256), 1);
+            hipLaunchKernelGGL((gemm_kernel<32, true, 256, 256>), grid2, dim3(256), sizeof(GemmSmemX3<32, 256>), st, *d, M);
+        } else if (x3) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, dim3(256), sizeof(GemmSmemX3<64>), st, *d, M);
         else hipLaunchKernelGGL((gemm_kernel<64, false>), grid, dim3(256), sizeof(GemmSmem<64>), st, *d, M);
     }
     GSDD_CHECK_LAUNCH();
