@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
 }
 
 // column sums: out[n] += sum_m Y[m][n]
-// out[n] += sum_r Y[r][n].  256 threads = cpb columns x (256 / cpb) row groups; 256 rows per block, LDS reduction over the row
+// out[n] += sum_r Y[r][n].  256 threads = cpb columns x (256 / cpb) row groups; CS_ROWS rows per block, LDS reduction over the row
 // groups, one atomic per column and block.
-constexpr int CS_ROWS = 256;
+constexpr int CS_ROWS = 64;    // rows per block: >= 1024 blocks at the training shapes (these kernels are latency-bound, not bandwidth-bound)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ld, int64_t M, int N, float* out, int cpb) {
     __shared__ float red[256];
     const int c = threadIdx.x % cpb, rg = threadIdx.x / cpb, nrg = 256 / cpb;
@@ -302,21 +302,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* q, const
 }
 
 // ------------------------------------------------------------------ embedding backward: demb[tok] += dx ; dpos[l] += dx
-__global__ void embed_bwd_kernel(const float* dx, const int64_t* tok, int64_t rows, int L, int D, int n_embed, float* demb,
-                                 float* dpos) {
-    const int q4 = D >> 2;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * q4) return;
-    const int64_t row = i / q4;
-    const int c = (int)(i % q4) * 4;
-    int64_t t = tok[row];
-    t = t < 0 ? 0 : (t >= n_embed ? n_embed - 1 : t);
-    const int l = (int)(row % L);
-    const float4 g = *reinterpret_cast<const float4*>(dx + row * D + c);
-    float* e = demb + t * D + c;
-    float* p = dpos + (int64_t)l * D + c;
-    atomicAdd(e + 0, g.x); atomicAdd(e + 1, g.y); atomicAdd(e + 2, g.z); atomicAdd(e + 3, g.w);
-    atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+// Half of x_t is the [MASK] token (id n_embed - 1) on average, so its table row would take tens of thousands of atomics on the
+// same 64 addresses; each block sums its [MASK] rows locally (registers, then LDS over the 16 row lanes) and issues one atomic
+// per column.  Block = 256 rows: thread (row lane tid >> 4, column quad tid & 15 [+16 ...]).
+constexpr int EB_ROWS = 256;
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* dx, const int64_t* tok, int64_t rows, int L, int D, int n_embed,
+                                                        float* demb, float* dpos) {
+    __shared__ float4 red[16][16];
+    const int rl = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * EB_ROWS;
+    const int hot = n_embed - 1;
+    for (int c = 4 * cq; c < D; c += 64) {
+        float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t row = r0 + rl; row < r0 + EB_ROWS && row < rows; row += 16) {
+            int64_t t = tok[row];
+            t = t < 0 ? 0 : (t >= n_embed ? n_embed - 1 : t);
+            const float4 g = *reinterpret_cast<const float4*>(dx + row * D + c);
+            float* p = dpos + (int64_t)(row % L) * D + c;
+            atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+            if (t == hot) {
+                hs.x += g.x; hs.y += g.y; hs.z += g.z; hs.w += g.w;
+            } else {
+                float* e = demb + t * D + c;
+                atomicAdd(e + 0, g.x); atomicAdd(e + 1, g.y); atomicAdd(e + 2, g.z); atomicAdd(e + 3, g.w);
+            }
+        }
+        red[rl][cq] = hs;
+        __syncthreads();
+        if (rl == 0) {
+            float4 a = red[0][cq];
+            for (int i = 1; i < 16; ++i) { const float4 b = red[i][cq]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            float* e = demb + (int64_t)hot * D + c;
+            atomicAdd(e + 0, a.x); atomicAdd(e + 1, a.y); atomicAdd(e + 2, a.z); atomicAdd(e + 3, a.w);
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ tiny linears over a handful of rows (one thread per output)
@@ -527,9 +547,9 @@ extern "C" int gsdd_d3pm_attention_bwd(const float* q, const float* k, const flo
 extern "C" int gsdd_d3pm_embed_bwd(const float* dx, const int64_t* tok, int B, int L, int D, int n_embed, float* demb,
                                    float* dpos, void* stream) {
     GSDD_CHECK_ARG(dx && tok && demb && dpos && B > 0 && L > 0 && D % 4 == 0, "bad args");
-    const int64_t n = (int64_t)B * L * (D / 4);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, tok,
-                       (int64_t)B * L, L, D, n_embed, demb, dpos);
+    const int64_t rows = (int64_t)B * L;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((rows + EB_ROWS - 1) / EB_ROWS)), dim3(256), 0, (hipStream_t)stream, dx, tok,
+                       rows, L, D, n_embed, demb, dpos);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }
