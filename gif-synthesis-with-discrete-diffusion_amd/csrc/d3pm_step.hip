@@ -398,8 +398,8 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
             const int k = 4 * lane + 256 * j + e;
             if (k < K) {
                 const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                sem += expf(qm[j][e] - mxm);
-                set += expf(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
+                sem += exp_le0(qm[j][e] - mxm);
+                set += exp_le0(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
             }
         }
     sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
@@ -420,12 +420,12 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
                 const float lm = clamp70(lae((qm[j][e] - Sm) + s.pca, s.pcb) + log_q1 + Sm);
                 const float lx0 = (k == x0 ? 0.f : LOG_ZERO);
                 const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
-                kl += expf(ltr) * (ltr - lm);
+                kl += exp_le0(ltr) * (ltr - lm);
                 const float w0 = (k == x0 ? 1.f : E30);
                 nll += w0 * lm;
                 aux += w0 * (lx0 - xr[j][e]);
                 if (lm > bestm) { bestm = lm; bestm_k = k; }
-                if (d.probs != nullptr) d.probs[((int64_t)b * (K + 1) + k) * d.L + l] = expf(lm);
+                if (d.probs != nullptr) d.probs[((int64_t)b * (K + 1) + k) * d.L + l] = exp_le0(lm);
             }
         }
     kl = wave_sum(kl); nll = wave_sum(nll); aux = wave_sum(aux);
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) se += (double)expf(a[j][e] - mx);
+            for (int e = 0; e < 4; ++e) se += (double)exp_le0(a[j][e] - mx);
         se = wave_sum(se);
         const double lse = (double)mx + log(se);
 #pragma unroll
@@ -603,8 +603,8 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
             const int k = 4 * lane + 256 * j + e;
             if (k < K) {
                 const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                sem += expf((clamp70(a[j][e]) - log_qt) - mxm);
-                set += expf(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
+                sem += exp_le0((clamp70(a[j][e]) - log_qt) - mxm);
+                set += exp_le0(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
             }
         }
     sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
@@ -628,9 +628,9 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
                 const float pre = ee + log_q1 + Sm;
                 const float lx0 = (k == x0 ? 0.f : LOG_ZERO);
                 const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
-                const float G = -(g_kl * expf(ltr) + g_nll * (k == x0 ? 1.f : E30));
+                const float G = -(g_kl * exp_le0(ltr) + g_nll * (k == x0 ? 1.f : E30));
                 const float Ge = (pre >= -70.f && pre <= 0.f) ? G : 0.f;
-                const float Gqn = Ge * expf((qn + s.pca) - ee);
+                const float Gqn = Ge * exp_le0((qn + s.pca) - ee);
                 gq[j][e] = Gqn;
                 sumGe += Ge; sumGqn += Gqn;
             }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
             if (k < K) {
                 const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
                 const float r = clamp70(a[j][e]);
-                const float pi = expf((r - log_qt) - Sm);
+                const float pi = exp_le0((r - log_qt) - Sm);
                 float Gr = gq[j][e] + GS * pi;
                 Gr -= g_aux * (k == x0 ? 1.f : E30);
                 const float Ga = (a[j][e] >= -70.f && a[j][e] <= 0.f) ? Gr : 0.f;
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
         const int k = 4 * lane + 256 * j;
         if (k < K) {
             float4 o;
-            o.x = gq[j][0] - expf(a[j][0]) * sumGa; o.y = gq[j][1] - expf(a[j][1]) * sumGa;
-            o.z = gq[j][2] - expf(a[j][2]) * sumGa; o.w = gq[j][3] - expf(a[j][3]) * sumGa;
+            o.x = gq[j][0] - exp_le0(a[j][0]) * sumGa; o.y = gq[j][1] - exp_le0(a[j][1]) * sumGa;
+            o.z = gq[j][2] - exp_le0(a[j][2]) * sumGa; o.w = gq[j][3] - exp_le0(a[j][3]) * sumGa;
             *reinterpret_cast<float4*>(drow + k) = o;
         }
     }
