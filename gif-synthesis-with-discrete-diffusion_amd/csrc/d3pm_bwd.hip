@@ -133,13 +133,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
 // column sums: out[n] += sum_m Y[m][n]
 // out[n] += sum_r Y[r][n].  256 threads = cpb columns x (256 / cpb) row groups; CS_ROWS rows per block, LDS reduction over the row
 // groups, one atomic per column and block.
-constexpr int CS_ROWS = 64;    // rows per block: >= 1024 blocks at the training shapes (these kernels are latency-bound, not bandwidth-bound)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ld, int64_t M, int N, float* out, int cpb) {
+constexpr int CS_ROWS = 64;    // rows per block for the per-batch sums; the column sums pick 64 (narrow and short: latency-bound, wants blocks)
+                               // or 256 (wide or long: fewer atomics per column) per launch
+__global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ld, int64_t M, int N, float* out, int cpb, int rows) {
     __shared__ float red[256];
     const int c = threadIdx.x % cpb, rg = threadIdx.x / cpb, nrg = 256 / cpb;
     const int n = blockIdx.y * cpb + c;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
-    const int64_t r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+    const int64_t r0 = (int64_t)blockIdx.x * rows;
+    const int64_t r1 = r0 + rows < M ? r0 + rows : M;
     float s = 0.f;
     if (n < N)
         for (int64_t r = r0 + rg; r < r1; r += nrg) s += Y[r * ld + n];
@@ -407,7 +408,6 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
 }
 
 // Adam over many tensors in one launch: table[b] = {p, g, m, v, n} for block b (up to ADAM_CHUNK elements of one tensor)
-constexpr int ADAM_CHUNK = 4096;
 __global__ __launch_bounds__(256) void adam_multi_kernel(const int64_t* __restrict__ table, float lr, float b1, float b2, float eps,
                                                          float bc1, float bc2) {
     const int64_t* e = table + (int64_t)blockIdx.x * 5;
@@ -471,9 +471,9 @@ extern "C" int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int
     hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, dW, slabs);
     GSDD_CHECK_LAUNCH();
     if (db != nullptr) {
-        const int cpb = colsum_cpb(N);
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + CS_ROWS - 1) / CS_ROWS), (N + cpb - 1) / cpb), dim3(256), 0,
-                           (hipStream_t)stream, dY, ldy, M, N, db, cpb);
+        const int cpb = colsum_cpb(N), rows = (N <= 256 && M < 262144) ? 64 : 256;
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows - 1) / rows), (N + cpb - 1) / cpb), dim3(256), 0,
+                           (hipStream_t)stream, dY, ldy, M, N, db, cpb, rows);
         GSDD_CHECK_LAUNCH();
     }
     return GSDD_OK;
@@ -481,9 +481,9 @@ extern "C" int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int
 
 extern "C" int gsdd_colsum(const float* Y, int ld, int64_t M, int N, float* out, void* stream) {
     GSDD_CHECK_ARG(Y && out && M > 0 && N > 0, "bad args");
-    const int cpb = colsum_cpb(N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + CS_ROWS - 1) / CS_ROWS), (N + cpb - 1) / cpb), dim3(256), 0,
-                       (hipStream_t)stream, Y, ld, M, N, out, cpb);
+    const int cpb = colsum_cpb(N), rows = (N <= 256 && M < 262144) ? 64 : 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows - 1) / rows), (N + cpb - 1) / cpb), dim3(256), 0,
+                       (hipStream_t)stream, Y, ld, M, N, out, cpb, rows);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }
