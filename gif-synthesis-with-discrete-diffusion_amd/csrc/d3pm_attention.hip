@@ -29,7 +29,9 @@ namespace gsdd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int KC = 256;            // keys per LDS chunk
+constexpr int KC = 256;            // keys per LDS chunk (exact-f32 kernel)
+// keys per LDS chunk of the matrix-pipe kernel = template parameter KC4 (384: 3 workgroups x 48 KB fill the CU's LDS; every
+// chunk boundary — barrier skew, overflow screen, pipeline refill — costs ~0.6 % of the run; GSDD_ATTN_KC=256 for A/B)
 constexpr float RESCALE_THR = 40.f;
 
 struct AttnSmem {
@@ -288,9 +290,10 @@ __global__ __launch_bounds__(256) void d3pm_attention_kernel(const float* __rest
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
+template <int KC4>
 struct AttnSmem4 {
-    uint4 k[2][KC][2];             // as AttnSmem.k
-    uint4 v[2][KC / 32][4][16];    // [buf][32-key pair-tile][key group g][col j] -> 8 f16: keys (tile0: 4g+r, tile1: 4g+r)
+    uint4 k[2][KC4][2];            // as AttnSmem.k
+    uint4 v[2][KC4 / 32][4][16];    // [buf][32-key pair-tile][key group g][col j] -> 8 f16: keys (tile0: 4g+r, tile1: 4g+r)
     uint4 ones[16];
 };
 
@@ -366,10 +369,11 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
     for (int j = 0; j < 16; ++j) dst[j * 8] = col[j];
 }
 
+template <int KC4>
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
                                                                 const uint4* __restrict__ vp, int B, int L, int H,
                                                                 float* __restrict__ out, float* __restrict__ lse) {
-    __shared__ AttnSmem4 sm;
+    __shared__ AttnSmem4<KC4> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqb = (L + 255) / 256;
     const unsigned nwg = gridDim.x;
@@ -405,24 +409,26 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         qfrag[j] = lg == 0 ? f0 : (lg == 1 ? f1 : (lg == 2 ? f2 : make_uint4(0u, 0u, 0u, 0u)));
     }
 
-    const int nchunks = (L + KC - 1) / KC;
-    // chunk staging = plain copy of the pre-split images: K 512 uint4 + V 512 uint4 per 256-key chunk
-    uint4 rk0, rk1, rv0, rv1;
+    const int nchunks = (L + KC4 - 1) / KC4;
+    // chunk staging = plain copy of the pre-split images: K 768 uint4 + V 768 uint4 per 384-key chunk
+    uint4 rk0, rk1, rk2, rv0, rv1, rv2;
     auto load_chunk = [&](int c) {
-        const int keys = min(KC, L - c * KC);                     // multiple of 32
+        const int keys = min(KC4, L - c * KC4);                   // multiple of 32
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        const uint4* ksrc = kph + (int64_t)c * KC * 2;
-        const uint4* vsrc = vph + (int64_t)c * (KC / 32) * 64;
+        const uint4* ksrc = kph + (int64_t)c * KC4 * 2;
+        const uint4* vsrc = vph + (int64_t)c * (KC4 / 32) * 64;
         rk0 = tid < keys * 2 ? ksrc[tid] : z;
         rk1 = tid + 256 < keys * 2 ? ksrc[tid + 256] : z;
+        rk2 = tid + 512 < keys * 2 ? ksrc[tid + 512] : z;
         rv0 = tid < keys * 2 ? vsrc[tid] : z;
         rv1 = tid + 256 < keys * 2 ? vsrc[tid + 256] : z;
+        rv2 = tid + 512 < keys * 2 ? vsrc[tid + 512] : z;
     };
     auto store_chunk = [&](int buf, int) {
         uint4* kd = &sm.k[buf][0][0];
         uint4* vd = &sm.v[buf][0][0][0];
-        kd[tid] = rk0; kd[tid + 256] = rk1;
-        vd[tid] = rv0; vd[tid + 256] = rv1;
+        kd[tid] = rk0; kd[tid + 256] = rk1; kd[tid + 512] = rk2;
+        vd[tid] = rv0; vd[tid + 256] = rv1; vd[tid + 512] = rv2;
     };
 
     f32x4 acc[4], sav[4];
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     const int slot = ((lg >> 1) ^ (li >> 3)) & 1;
     const uint4* kbase0 = (lg == 3) ? &sm.ones[(li >= 4 && li < 12) ? 0 : 1] : &sm.k[0][li][slot];
     const int kstep = (lg == 3) ? 0 : 32;
-    const int kbuf = (lg == 3) ? 0 : KC * 2;
+    const int kbuf = (lg == 3) ? 0 : KC4 * 2;
     {   // m = ceil(max over the first 64 keys) - 3, shared by the 4 key groups of a query
         const int nt0 = min(4, L >> 4);
 #pragma unroll
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(c + 1);
-        const int npairs = min(KC, L - c * KC) >> 5;
+        const int npairs = min(KC4, L - c * KC4) >> 5;
         const uint4* kb = kbase0 + buf * kbuf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) sav[j] = acc[j];
@@ -483,11 +489,11 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
                 }
             }
             // overflow screen (f16 hi part saturated to inf somewhere in this chunk): rare
-            bool bad = false;
+            // (inf and NaN survive additions, and full-rate adds are cheaper than sixteen half-rate compares)
+            float chk = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bad = bad || !(fabsf(acc[j][r]) < 3.0e38f);
+            for (int j = 0; j < 4; ++j) chk += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
+            const bool bad = !(fabsf(chk) < 3.0e38f);
             if (!__any(bad)) break;
             // rare path: exact maximum of this chunk's scores per query (relative to the current m), then move m so that
             // the chunk maximum lands in (2^2, 2^3]; accumulators restart from the chunk-start copy scaled by 2^-delta.
@@ -597,7 +603,9 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
         uint4* vp = kp + rows * 2;
         hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
         GSDD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(d3pm_attention_v4_kernel, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
+        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);
     }
@@ -619,7 +627,7 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     uint4* vp = kp + rows * 2;
     hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
     GSDD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(d3pm_attention_v4_kernel, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
+    hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
                        out, lse);
     GSDD_CHECK_LAUNCH();
     *done = 1;
