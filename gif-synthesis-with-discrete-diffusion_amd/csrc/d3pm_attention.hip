@@ -413,16 +413,14 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     // chunk staging = plain copy of the pre-split images: K 768 uint4 + V 768 uint4 per 384-key chunk
     uint4 rk0, rk1, rk2, rv0, rv1, rv2;
     auto load_chunk = [&](int c) {
-        const int keys = min(KC4, L - c * KC4);                   // multiple of 32
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        // Unconditional loads from a clamped index: a load under "cond ? p[i] : zero" becomes a *flat* load from either the
+        // image or a scratch copy of the zero, and flat loads also count on lgkmcnt, so the first LDS fragment wait of the chunk
+        // would wait for global memory.  Rows past a short last chunk are staged but never read (npairs bounds the tile loop).
+        const int last = 2 * min(KC4, L - c * KC4) - 1;           // keys: a multiple of 32
         const uint4* ksrc = kph + (int64_t)c * KC4 * 2;
         const uint4* vsrc = vph + (int64_t)c * (KC4 / 32) * 64;
-        rk0 = tid < keys * 2 ? ksrc[tid] : z;
-        rk1 = tid + 256 < keys * 2 ? ksrc[tid + 256] : z;
-        rk2 = tid + 512 < keys * 2 ? ksrc[tid + 512] : z;
-        rv0 = tid < keys * 2 ? vsrc[tid] : z;
-        rv1 = tid + 256 < keys * 2 ? vsrc[tid + 256] : z;
-        rv2 = tid + 512 < keys * 2 ? vsrc[tid + 512] : z;
+        rk0 = ksrc[min(tid, last)]; rk1 = ksrc[min(tid + 256, last)]; rk2 = ksrc[min(tid + 512, last)];
+        rv0 = vsrc[min(tid, last)]; rv1 = vsrc[min(tid + 256, last)]; rv2 = vsrc[min(tid + 512, last)];
     };
     auto store_chunk = [&](int buf, int) {
         uint4* kd = &sm.k[buf][0][0];

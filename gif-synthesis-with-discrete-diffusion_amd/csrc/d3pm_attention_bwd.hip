@@ -207,15 +207,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(const float* _
     const int nchunks = (L + BKC - 1) / BKC;
     uint4 r0, r1, r2, r3, r4, r5;
     auto load_chunk = [&](int ch) {
-        const int keys = min(BKC, L - ch * BKC);                      // multiple of 32
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        // unconditional loads from a clamped index (a "cond ? p[i] : zero" load turns into a flat load, which also counts on
+        // lgkmcnt and stalls the chunk's first LDS wait); rows past a short last chunk are staged but never read
+        const int last = 2 * min(BKC, L - ch * BKC) - 1;              // keys: a multiple of 32
         const uint4* ks = im.kp + (hrow0 + (int64_t)ch * BKC) * 2;
         const uint4* vs = im.vk + (hrow0 + (int64_t)ch * BKC) * 2;
         const uint4* kvs = im.kv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
-        const bool a0 = tid < keys * 2, a1 = tid + 256 < keys * 2;
-        r0 = a0 ? ks[tid] : z; r1 = a1 ? ks[tid + 256] : z;
-        r2 = a0 ? vs[tid] : z; r3 = a1 ? vs[tid + 256] : z;
-        r4 = a0 ? kvs[tid] : z; r5 = a1 ? kvs[tid + 256] : z;
+        const int i0 = min(tid, last), i1 = min(tid + 256, last);
+        r0 = ks[i0]; r1 = ks[i1];
+        r2 = vs[i0]; r3 = vs[i1];
+        r4 = kvs[i0]; r5 = kvs[i1];
     };
     auto store_chunk = [&](int buf) {
         uint4* kd = &sm.k[buf][0][0];
@@ -328,17 +329,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
     uint4 rq0, rq1, rq2, rg0, rg1, rg2, rqv0, rqv1, rgv0, rgv1;
     auto load_chunk = [&](int ch) {
         const int rows = min(BKC, L - ch * BKC);                      // multiple of 32
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         const uint4* qs = im.qp + (hrow0 + (int64_t)ch * BKC) * 3;
         const uint4* gs = im.gp + (hrow0 + (int64_t)ch * BKC) * 3;
         const uint4* qvs = im.qv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
         const uint4* gvs = im.gv + ((hrow0 + (int64_t)ch * BKC) >> 5) * 64;
-        const bool a0 = tid < rows * 3, a1 = tid + 256 < rows * 3, a2 = tid + 512 < rows * 3;
-        const bool b0 = tid < rows * 2, b1 = tid + 256 < rows * 2;
-        rq0 = a0 ? qs[tid] : z; rq1 = a1 ? qs[tid + 256] : z; rq2 = a2 ? qs[tid + 512] : z;
-        rg0 = a0 ? gs[tid] : z; rg1 = a1 ? gs[tid + 256] : z; rg2 = a2 ? gs[tid + 512] : z;
-        rqv0 = b0 ? qvs[tid] : z; rqv1 = b1 ? qvs[tid + 256] : z;
-        rgv0 = b0 ? gvs[tid] : z; rgv1 = b1 ? gvs[tid + 256] : z;
+        // unconditional, clamped (see the dQ kernel)
+        const int l3 = rows * 3 - 1, l2 = rows * 2 - 1;
+        const int a0 = min(tid, l3), a1 = min(tid + 256, l3), a2 = min(tid + 512, l3);
+        const int b0 = min(tid, l2), b1 = min(tid + 256, l2);
+        rq0 = qs[a0]; rq1 = qs[a1]; rq2 = qs[a2];
+        rg0 = gs[a0]; rg1 = gs[a1]; rg2 = gs[a2];
+        rqv0 = qvs[b0]; rqv1 = qvs[b1];
+        rgv0 = gvs[b0]; rgv1 = gvs[b1];
     };
     auto store_chunk = [&](int buf) {
         uint4* qd = &sm.q[buf][0][0];
