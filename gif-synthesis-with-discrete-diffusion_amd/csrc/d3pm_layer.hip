@@ -39,6 +39,8 @@ struct LayerArgs {
     const int64_t* t2;         // [B2]
     const float* wqkv; const float* bqkv;  // [192][64], [192]
     float* qkv;                // [48][M][4]
+    const uint4* w2_x3;        // optional fragment images (gsdd_d3pm_layer_pack)
+    const uint4* wqkv_x3;
 };
 
 // GELU2 (transformer_utils.py:115-119): v * sigmoid(1.702 v) = v / (1 + 2^(-1.702 log2(e) v)).
@@ -348,6 +350,559 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same fused layer with every GEMM on the bf16 matrix pipe: each f32 operand element is split error-free into three
+// bf16 pieces (x = x1 + x2 + x3, round-to-nearest pieces, exact residuals) and a k-step of 16 is the six significant cross
+// products on v_mfma_f32_32x32x16_bf16 — the scheme of gemm.hip, results indistinguishable from the f32 kernel.  Why it pays
+// here: on f32 operands the MFMA and the VALU share one datapath, so this kernel's 196 k MFMA cycles and 46 k VALU cycles per
+// SIMD add up; the bf16 products take 6 x 32 cycles instead of 8 x 64 per 32 x 32 x 16 block and run beside the VALU, which now
+// also does the splits (weights are split once per 32-row group as they are read from LDS, activations once per GEMM input).
+// The accumulator layout of the 32x32x16 MFMA is that of the 32x32x2 one, so the register chaining between the GEMMs and all
+// epilogues are unchanged: accumulator registers 8s .. 8s+7 of a 32-feature tile are the B fragment of k-step s, and the
+// matching weight fragment is the two float4 runs [16s + 4h, +4) and [16s + 8 + 4h, +4) of the weight row.
+typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+struct P3 { lbf16x8 p[3]; };
+__device__ __forceinline__ P3 split8(const float (&x)[8]) {
+    P3 o;
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = x[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.p[i][j] = (__bf16)r[j];
+        if (i < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] -= (float)o.p[i][j];
+        }
+    }
+    return o;
+}
+__device__ __forceinline__ void mma6(const P3& a, const P3& b, f32x16& acc) {   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], acc, 0, 0, 0);
+}
+// the four k-steps (t, s) of a 64-feature activation held as act[16t + 8s + j]
+__device__ __forceinline__ void split_act(const float (&act)[32], P3 (&b)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act[8 * q + j];
+        b[q] = split8(v);
+    }
+}
+// acc[nt] += W[32 nt + li][k0 + 32 t + 16 s + ...] * (k-step q = 2t + s of the activation), weights f32 in LDS or global memory
+__device__ __forceinline__ void step_x3(const float* w, int pitch, int k0, int q, int li, int h, const P3& b, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float* row = w + (int64_t)(32 * nt + li) * pitch + k0 + 16 * q + 4 * h;
+        const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
+        const float wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        mma6(split8(wv), b, acc[nt]);
+    }
+}
+__device__ __forceinline__ void gemm64_x3(const float* w, int pitch, int k0, int li, int h, const P3 (&b)[4], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) step_x3(w, pitch, k0, q, li, h, b[q], acc);
+}
+
+template <bool HAS_QKV>
+__global__ __launch_bounds__(512, 1) void d3pm_layer_x3_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sw1 = lds;                    // [256][68]
+    float* sw2 = lds + LDS_W2;           // [64][260]
+    float* swp = lds + LDS_WP;           // [64][68]
+    float* par = lds + LDS_PAR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    float* scr = lds + LDS_SCR + wave * 192;
+
+    for (int i = tid; i < HID * (D / 4); i += 512) {
+        const int n = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<float4*>(&sw1[n * W1P + c]) = *reinterpret_cast<const float4*>(a.w1 + n * D + c);
+    }
+    for (int i = tid; i < D * (HID / 4); i += 512) {
+        const int n = i >> 6, c = (i & 63) * 4;
+        *reinterpret_cast<float4*>(&sw2[n * W2P + c]) = *reinterpret_cast<const float4*>(a.w2 + n * HID + c);
+    }
+    for (int i = tid; i < D * (D / 4); i += 512) {
+        const int n = i >> 4, c = (i & 15) * 4;
+        *reinterpret_cast<float4*>(&swp[n * W1P + c]) = *reinterpret_cast<const float4*>(a.wproj + n * D + c);
+    }
+    for (int i = tid; i < PAR_N; i += 512) {
+        float v;
+        if (i < PAR_G2) v = a.bproj[i];
+        else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2];
+        else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN];
+        else if (i < PAR_B2) v = a.b1[i - PAR_B1];
+        else if (i < PAR_BQKV) v = a.b2[i - PAR_B2];
+        else v = HAS_QKV ? a.bqkv[i - PAR_BQKV] : 0.f;
+        par[i] = v;
+    }
+    __syncthreads();
+
+    const int64_t ngroups = (a.M + 31) / 32;
+    const bool batch_uniform = a.L % 32 == 0;
+    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
+        const int64_t m = grp * 32 + li;
+        const bool valid = m < a.M;
+        const bool full = grp * 32 + 32 <= a.M;
+        const int64_t mc = valid ? m : a.M - 1;
+        const int b = (int)((uint32_t)mc / (uint32_t)a.L);
+        if (batch_uniform) {
+            const int bu = (int)((uint32_t)(grp * 32) / (uint32_t)a.L);
+            if (lane < 16) {
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)bu * D + 4 * lane);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = cv;
+            } else if (HAS_QKV && lane < 48) {
+                const float* tab = a.ada + a.t2[bu] * (2 * D);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = *reinterpret_cast<const float4*>(tab + 4 * (lane - 16));
+            }
+        }
+
+        float act[32], x1[32];
+        f32x16 acc[2];
+        P3 bp[4];
+        // ---- x1 = x + proj(y) + b_proj + cvec[b]
+        load_frag(a.y + mc * D, h, act);
+        load_frag(a.x + mc * D, h, x1);
+        split_act(act, bp);
+        zero2(acc);
+        gemm64_x3(swp, W1P, 0, li, h, bp, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bpj = *reinterpret_cast<const float4*>(par + PAR_BPROJ + f);
+                float4 cv;
+                if (batch_uniform) cv = *reinterpret_cast<const float4*>(scr + f);
+                else cv = a.cvec != nullptr ? *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += (acc[t][r + 0] + bpj.x) + cv.x;
+                x1[16 * t + r + 1] += (acc[t][r + 1] + bpj.y) + cv.y;
+                x1[16 * t + r + 2] += (acc[t][r + 2] + bpj.z) + cv.z;
+                x1[16 * t + r + 3] += (acc[t][r + 3] + bpj.w) + cv.w;
+            }
+        // ---- h = LN2(x1) * gamma + beta
+        float mean, rstd;
+        row_norm(x1, mean, rstd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 gm = *reinterpret_cast<const float4*>(par + PAR_G2 + f);
+                const float4 bt = *reinterpret_cast<const float4*>(par + PAR_B2LN + f);
+                const int r = 16 * t + 4 * g;
+                act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+            }
+        split_act(act, bp);
+        // ---- MLP in 4 chunks of 64 hidden units; each k-step of the W2 product takes its 8 GELU2 outputs straight from the
+        //      W1 accumulators, splits them and is done with them
+        f32x16 acc3[2];
+        zero2(acc3);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            zero2(acc);
+            gemm64_x3(sw1 + c * 64 * W1P, W1P, 0, li, h, bp, acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = q >> 1, s = q & 1;
+                const float4 b0 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s + 4 * h);
+                const float4 b1 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s + 8 + 4 * h);
+                const float u[8] = {gelu2(acc[t][8 * s + 0] + b0.x), gelu2(acc[t][8 * s + 1] + b0.y), gelu2(acc[t][8 * s + 2] + b0.z),
+                                    gelu2(acc[t][8 * s + 3] + b0.w), gelu2(acc[t][8 * s + 4] + b1.x), gelu2(acc[t][8 * s + 5] + b1.y),
+                                    gelu2(acc[t][8 * s + 6] + b1.z), gelu2(acc[t][8 * s + 7] + b1.w)};
+                step_x3(sw2, W2P, 64 * c, q, li, h, split8(u), acc3);
+            }
+        }
+        // ---- x2 = x1 + mlp + b2 -> x
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B2 + f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += acc3[t][r + 0] + bb.x;
+                x1[16 * t + r + 1] += acc3[t][r + 1] + bb.y;
+                x1[16 * t + r + 2] += acc3[t][r + 2] + bb.z;
+                x1[16 * t + r + 3] += acc3[t][r + 3] + bb.w;
+            }
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        } else if (valid) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        }
+        if (HAS_QKV) {
+            row_norm(x1, mean, rstd);
+            const float* tab = a.ada + a.t2[b] * (2 * D);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = 32 * t + 8 * g + 4 * h;
+                    float4 gm, bt;
+                    if (batch_uniform) {
+                        gm = *reinterpret_cast<const float4*>(scr + 64 + f);
+                        bt = *reinterpret_cast<const float4*>(scr + 128 + f);
+                    } else {
+                        gm = *reinterpret_cast<const float4*>(tab + f);
+                        bt = *reinterpret_cast<const float4*>(tab + D + f);
+                    }
+                    const int r = 16 * t + 4 * g;
+                    act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                    act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                    act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                    act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+                }
+            split_act(act, bp);
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                // all 16 weight fragments of the 64 x 64 block are requested before the first split (one L2 round trip)
+                const float* wq = a.wqkv + (int64_t)c * 64 * D;
+                float4 w0[8], w1[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w0[2 * q] = *reinterpret_cast<const float4*>(wq + (int64_t)li * D + 16 * q + 4 * h);
+                    w0[2 * q + 1] = *reinterpret_cast<const float4*>(wq + (int64_t)li * D + 16 * q + 8 + 4 * h);
+                    w1[2 * q] = *reinterpret_cast<const float4*>(wq + (int64_t)(32 + li) * D + 16 * q + 4 * h);
+                    w1[2 * q + 1] = *reinterpret_cast<const float4*>(wq + (int64_t)(32 + li) * D + 16 * q + 8 + 4 * h);
+                }
+                zero2(acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0[8] = {w0[2 * q].x, w0[2 * q].y, w0[2 * q].z, w0[2 * q].w, w0[2 * q + 1].x, w0[2 * q + 1].y, w0[2 * q + 1].z, w0[2 * q + 1].w};
+                    const float v1[8] = {w1[2 * q].x, w1[2 * q].y, w1[2 * q].z, w1[2 * q].w, w1[2 * q + 1].x, w1[2 * q + 1].y, w1[2 * q + 1].z, w1[2 * q + 1].w};
+                    mma6(split8(v0), bp[q], acc[0]);
+                    mma6(split8(v1), bp[q], acc[1]);
+                }
+                float4 o[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int t = q >> 2, r = 4 * (q & 3);
+                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
+                    o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
+                }
+                if (full) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                } else if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Third variant: the weights arrive as bf16x3 *fragment images*, so no weight is ever split inside the row loop.
+// An image is a sequence of fragments; fragment f holds, for each of its three pieces p and each lane l, the 16 bytes
+// (8 bf16) that lane feeds to v_mfma_f32_32x32x16_bf16 as its A operand: byte offset ((3 f + p) * 64 + l) * 16.
+// Fragment (q, nt) of a 64-output x 64-input block W: lane (li = l & 31, h = l >> 5), element j ->
+// W[32 nt + li][16 q + 8 (j >> 2) + 4 h + (j & 3)]  (the k order of an accumulator tile used as the B operand).
+//   W1    [256][64]: f = (4 c + q) * 2 + nt, block c = rows 64 c ..       split into LDS by the workgroup at start (96 KB, resident)
+//   layer image (gsdd_d3pm_layer_pack, global): W2 [64][256] as 4 column blocks of 8 fragments (f = 8 c + 2 q + nt), then
+//                                               Wproj [64][64] (8 fragments, f = 2 q + nt; copied to LDS at start)
+//   qkv image (global): Wqkv [192][64] as 3 row blocks of 8 fragments
+// W2 and Wqkv fragments are read from L2 straight into registers, requested one k-step (W2) / two k-steps (Wqkv) before use.
+// (A variant that passed them through a two-slot LDS ring shared by the eight waves, one barrier per 24 KB block, measured
+// slower: 0.123 vs 0.109 ms — the barriers and the extra register pressure cost more than the L2 latency they hide.)
+// What is left on the VALU per row group is the splits of the four GEMM inputs and the elementwise work.
+constexpr int IMG_FRAG_U4 = 3 * 64;                          // uint4 per fragment
+constexpr int IMG_BLOCK_U4 = 8 * IMG_FRAG_U4;                // a stage's block: 8 fragments = 1536 uint4 = 24 KB
+constexpr int X3P_W1_U4 = 32 * IMG_FRAG_U4;
+constexpr int X3P_PAR_OFF = (X3P_W1_U4 + IMG_BLOCK_U4) * 4;       // float offset of the parameter block (after W1 + Wproj images)
+constexpr int X3P_SCR_OFF = X3P_PAR_OFF + PAR_N;
+constexpr int X3P_LDS_FLOATS = X3P_SCR_OFF + 8 * 192;
+
+__device__ __forceinline__ P3 split8_w(const float* row) {    // row -> W[..][16 q + 4 h]: two float4 runs, 8 floats apart
+    const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
+    const float wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return split8(wv);
+}
+__device__ __forceinline__ void store_frag(uint4* img, int f, int l, const P3& a) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) img[(3 * f + i) * 64 + l] = __builtin_bit_cast(uint4, a.p[i]);
+}
+__device__ __forceinline__ P3 load_frag3(const uint4* img, int f, int l) {
+    P3 a;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.p[i] = __builtin_bit_cast(lbf16x8, img[(3 * f + i) * 64 + l]);
+    return a;
+}
+
+// one thread per (fragment, lane): 32 fragments of W2 + 8 of Wproj -> layer image, 24 of Wqkv -> qkv image
+__global__ __launch_bounds__(256) void layer_pack_kernel(const float* w2, const float* wproj, const float* wqkv, uint4* lay_x3,
+                                                         uint4* wqkv_x3) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int nL = 40 * 64, nQ = wqkv != nullptr ? 24 * 64 : 0;
+    if (u >= nL + nQ) return;
+    const bool is_q = u >= nL;
+    const int v = is_q ? u - nL : u;
+    const int f = v >> 6, l = v & 63, li = l & 31, h = l >> 5;
+    const int nt = f & 1, q = (f >> 1) & 3, c = f >> 3;
+    if (is_q) store_frag(wqkv_x3, f, l, split8_w(wqkv + (int64_t)(64 * c + 32 * nt + li) * D + 16 * q + 4 * h));
+    else if (f < 32) store_frag(lay_x3, f, l, split8_w(w2 + (int64_t)(32 * nt + li) * HID + 64 * c + 16 * q + 4 * h));
+    else store_frag(lay_x3, f, l, split8_w(wproj + (int64_t)(32 * nt + li) * D + 16 * q + 4 * h));
+}
+
+// acc[nt] += (fragments f0 .. f0+7 of an LDS image) x the four k-steps of bp; the next fragment's three ds_read_b128 are
+// issued before the current fragment's six MFMAs
+__device__ __forceinline__ void gemm_lds_img(const uint4* img, int f0, int lane, const P3 (&bp)[4], f32x16 (&acc)[2]) {
+    P3 cur = load_frag3(img, f0, lane);
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) {
+        const P3 nxt = load_frag3(img, f0 + (ts < 7 ? ts + 1 : 0), lane);
+        mma6(cur, bp[ts >> 1], acc[ts & 1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // the three reads first,
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);     // then the six MFMAs
+        cur = nxt;
+    }
+}
+
+template <bool HAS_QKV>
+__global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4* iw1 = reinterpret_cast<uint4*>(lds);              // 32 fragments
+    uint4* iwp = iw1 + X3P_W1_U4;                            // 8 fragments
+    float* par = lds + X3P_PAR_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    float* scr = lds + X3P_SCR_OFF + wave * 192;
+    const uint4* img_w2 = a.w2_x3;                           // 32 fragments, then Wproj's 8
+    const uint4* img_qkv = a.wqkv_x3;                        // 24 fragments
+
+    // ---- W1 is split by the workgroup once; Wproj's fragments are copied from the layer image
+    for (int u = tid; u < 32 * 64; u += 512) {
+        const int f = u >> 6, l = u & 63, fl = l & 31, fh = l >> 5;
+        const int nt = f & 1, q = (f >> 1) & 3, c = f >> 3;
+        store_frag(iw1, f, l, split8_w(a.w1 + (int64_t)(64 * c + 32 * nt + fl) * D + 16 * q + 4 * fh));
+    }
+    for (int u = tid; u < IMG_BLOCK_U4; u += 512) iwp[u] = img_w2[4 * IMG_BLOCK_U4 + u];
+    for (int i = tid; i < PAR_N; i += 512) {
+        float v;
+        if (i < PAR_G2) v = a.bproj[i];
+        else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2];
+        else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN];
+        else if (i < PAR_B2) v = a.b1[i - PAR_B1];
+        else if (i < PAR_BQKV) v = a.b2[i - PAR_B2];
+        else v = HAS_QKV ? a.bqkv[i - PAR_BQKV] : 0.f;
+        par[i] = v;
+    }
+    __syncthreads();
+
+    const int64_t ngroups = (a.M + 31) / 32;
+    const bool batch_uniform = a.L % 32 == 0;
+    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
+        const int64_t m = grp * 32 + li;
+        const bool valid = m < a.M;
+        const bool full = grp * 32 + 32 <= a.M;
+        const int64_t mc = valid ? m : a.M - 1;
+        const int b = (int)((uint32_t)mc / (uint32_t)a.L);
+        if (batch_uniform) {
+            const int bu = (int)((uint32_t)(grp * 32) / (uint32_t)a.L);
+            if (lane < 16) {
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)bu * D + 4 * lane);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = cv;
+            } else if (HAS_QKV && lane < 48) {
+                const float* tab = a.ada + a.t2[bu] * (2 * D);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = *reinterpret_cast<const float4*>(tab + 4 * (lane - 16));
+            }
+        }
+
+        float act[32], x1[32];
+        f32x16 acc[2];
+        P3 bp[4];
+        // W2 fragments come from L2: tile 0 of a k-step is requested during the previous k-step, tile 1 at the start of its own
+        // (deeper prefetch spills: registers, not L2 latency, are the scarce resource here); the first one is in flight during
+        // proj / LN / W1
+        P3 w2a = load_frag3(img_w2, 0, lane);
+        // ---- x1 = x + proj(y) + b_proj + cvec[b]
+        load_frag(a.y + mc * D, h, act);
+        load_frag(a.x + mc * D, h, x1);
+        split_act(act, bp);
+        zero2(acc);
+        gemm_lds_img(iwp, 0, lane, bp, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bpj = *reinterpret_cast<const float4*>(par + PAR_BPROJ + f);
+                float4 cv;
+                if (batch_uniform) cv = *reinterpret_cast<const float4*>(scr + f);
+                else cv = a.cvec != nullptr ? *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += (acc[t][r + 0] + bpj.x) + cv.x;
+                x1[16 * t + r + 1] += (acc[t][r + 1] + bpj.y) + cv.y;
+                x1[16 * t + r + 2] += (acc[t][r + 2] + bpj.z) + cv.z;
+                x1[16 * t + r + 3] += (acc[t][r + 3] + bpj.w) + cv.w;
+            }
+        // ---- h = LN2(x1) * gamma + beta
+        float mean, rstd;
+        row_norm(x1, mean, rstd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 gm = *reinterpret_cast<const float4*>(par + PAR_G2 + f);
+                const float4 bt = *reinterpret_cast<const float4*>(par + PAR_B2LN + f);
+                const int r = 16 * t + 4 * g;
+                act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+            }
+        split_act(act, bp);
+        // ---- MLP in 4 chunks of 64 hidden units
+        f32x16 acc3[2];
+        zero2(acc3);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            zero2(acc);
+            gemm_lds_img(iw1, 8 * c, lane, bp, acc);
+            // GELU2 + split of k-step q + 1 is issued between the MFMAs of k-step q (both tiles), so the matrix pipe stays busy
+            // while the VALU prepares its next operand
+            auto make_ub = [&](int q) {
+                const int t = q >> 1, s2 = q & 1;
+                const float4 b0 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s2 + 4 * h);
+                const float4 b1 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s2 + 8 + 4 * h);
+                const float u[8] = {gelu2(acc[t][8 * s2 + 0] + b0.x), gelu2(acc[t][8 * s2 + 1] + b0.y), gelu2(acc[t][8 * s2 + 2] + b0.z),
+                                    gelu2(acc[t][8 * s2 + 3] + b0.w), gelu2(acc[t][8 * s2 + 4] + b1.x), gelu2(acc[t][8 * s2 + 5] + b1.y),
+                                    gelu2(acc[t][8 * s2 + 6] + b1.z), gelu2(acc[t][8 * s2 + 7] + b1.w)};
+                return split8(u);
+            };
+            P3 ub = make_ub(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 8 * c + 2 * q;
+                const P3 w2b = load_frag3(img_w2, f0 + 1, lane);
+                const P3 na = load_frag3(img_w2, f0 + 2 < 32 ? f0 + 2 : 0, lane);
+                P3 ubn = ub;
+                if (q < 3) ubn = make_ub(q + 1);
+                mma6(w2a, ub, acc3[0]);
+                mma6(w2b, ub, acc3[1]);
+                if (q < 3) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // ... then a slice of the next operand's VALU work
+                    }
+                }
+                ub = ubn;
+                w2a = na;
+            }
+        }
+        // ---- x2 = x1 + mlp + b2 -> x
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B2 + f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += acc3[t][r + 0] + bb.x;
+                x1[16 * t + r + 1] += acc3[t][r + 1] + bb.y;
+                x1[16 * t + r + 2] += acc3[t][r + 2] + bb.z;
+                x1[16 * t + r + 3] += acc3[t][r + 3] + bb.w;
+            }
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        } else if (valid) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        }
+        if (HAS_QKV) {
+            // Wqkv fragments come from L2 two tile-steps ahead of their use; the first two are requested before the AdaLN arithmetic
+            P3 wq0 = load_frag3(img_qkv, 0, lane), wq1 = load_frag3(img_qkv, 1, lane);
+            row_norm(x1, mean, rstd);
+            const float* tab = a.ada + a.t2[b] * (2 * D);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = 32 * t + 8 * g + 4 * h;
+                    float4 gm, bt;
+                    if (batch_uniform) {
+                        gm = *reinterpret_cast<const float4*>(scr + 64 + f);
+                        bt = *reinterpret_cast<const float4*>(scr + 128 + f);
+                    } else {
+                        gm = *reinterpret_cast<const float4*>(tab + f);
+                        bt = *reinterpret_cast<const float4*>(tab + D + f);
+                    }
+                    const int r = 16 * t + 4 * g;
+                    act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                    act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                    act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                    act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+                }
+            split_act(act, bp);
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                zero2(acc);
+#pragma unroll
+                for (int ts = 0; ts < 8; ++ts) {
+                    const int fn = 8 * c + ts + 2;                 // (wraps to fragment 0 / 1 after the last block: harmless)
+                    const P3 wq2 = load_frag3(img_qkv, fn < 24 ? fn : fn - 24, lane);
+                    mma6(wq0, bp[ts >> 1], acc[ts & 1]);
+                    wq0 = wq1; wq1 = wq2;
+                }
+                float4 o[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int t = q >> 2, r = 4 * (q & 3);
+                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
+                    o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
+                }
+                if (full) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                } else if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // to_logits: logits[m][:] = W LN(x[m]) + b  (nn.LayerNorm(64) + nn.Linear(64 -> K), transformer_utils.py:353-356,442).
 // Same transposed-GEMM register layout: a wave owns 32 rows, normalises them in registers once and sweeps all K
 // output features; W streams through LDS in 256-feature chunks shared by the 8 waves (double-buffered).
@@ -509,10 +1064,43 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     if (!attr_done) {
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    a.w2_x3 = reinterpret_cast<const uint4*>(d->w2_x3); a.wqkv_x3 = reinterpret_cast<const uint4*>(d->wqkv_x3);
+    // GSDD_LAYER=f32 | x3 | x3p forces a variant (A/B); default: fragment images when the caller packed them, else on-the-fly splits
+    static const char* force = getenv("GSDD_LAYER");
+    const bool have_img = d->w2_x3 != nullptr && (!has_qkv || d->wqkv_x3 != nullptr);
+    const int variant = force == nullptr ? (have_img ? 2 : 1) : (force[0] == 'f' ? 0 : ((force[2] == 'p' && have_img) ? 2 : 1));
+    if (variant == 0) {
+        if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    } else if (variant == 1) {
+        if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(d3pm_layer_x3_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+        const size_t ldsp = (size_t)X3P_LDS_FLOATS * sizeof(float);
+        static bool attr_p = false;
+        if (!attr_p) {
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+            attr_p = true;
+        }
+        if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3p_kernel<true>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(d3pm_layer_x3p_kernel<false>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
+    }
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_d3pm_layer_pack(const float* w2, const float* wproj, const float* wqkv, void* layer_x3, void* wqkv_x3,
+                                    void* stream) {
+    GSDD_CHECK_ARG(w2 != nullptr && wproj != nullptr && layer_x3 != nullptr, "null pointer");
+    GSDD_CHECK_ARG((wqkv == nullptr) == (wqkv_x3 == nullptr), "wqkv and its image come together");
+    const int units = (40 + (wqkv != nullptr ? 24 : 0)) * 64;
+    hipLaunchKernelGGL(layer_pack_kernel, dim3((units + 255) / 256), dim3(256), 0, (hipStream_t)stream, w2, wproj, wqkv,
+                       reinterpret_cast<uint4*>(layer_x3), reinterpret_cast<uint4*>(wqkv_x3));
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

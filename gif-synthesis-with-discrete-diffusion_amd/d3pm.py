@@ -147,6 +147,8 @@ class Text2ImageTransformer(nn.Module):
                 g2=blk.ln2.weight.contiguous(), b2=blk.ln2.bias.contiguous(),
                 w1=blk.mlp[0].weight.contiguous(), bb1=blk.mlp[0].bias.contiguous(),
                 w2=blk.mlp[2].weight.contiguous(), bb2=blk.mlp[2].bias.contiguous())
+            if lay["w2"].shape == (64, 256) and lay["wqkv"].shape == (192, 64):       # the fused layer kernel's shape
+                lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
             p["layers"].append(lay)
         p["gf"], p["bf"] = self.to_logits[0].weight.contiguous(), self.to_logits[0].bias.contiguous()
         p["wl"], p["bl"] = self.to_logits[1].weight.contiguous(), self.to_logits[1].bias.contiguous()

@@ -176,9 +176,22 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, stream=None
     d.cvec = ptr(cvec)
     d.wproj, d.bproj, d.ln2_g, d.ln2_b = ptr(lay["wproj"]), ptr(lay["bproj"]), ptr(lay["g2"]), ptr(lay["b2"])
     d.w1, d.b1, d.w2, d.b2 = ptr(lay["w1"]), ptr(lay["bb1"]), ptr(lay["w2"]), ptr(lay["bb2"])
+    d.w2_x3 = ptr(lay.get("w2_x3"))
     if nxt is not None:
         d.ada, d.t2, d.wqkv, d.bqkv, d.qkv = ptr(nxt["ada1"]), ptr(t2), ptr(nxt["wqkv"]), ptr(nxt["bqkv"]), ptr(qkv)
+        d.wqkv_x3 = ptr(nxt.get("wqkv_x3"))
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
+
+
+LAYER_X3_BYTES, WQKV_X3_BYTES = 40 * 3 * 1024, 24 * 3 * 1024
+
+
+def d3pm_layer_pack(w2, wproj, wqkv, stream=None):
+    """bf16x3 fragment images for the fused layer kernel: (w2 + wproj of a block, wqkv of a block); valid until the weights change."""
+    lay_x3 = torch.empty((LAYER_X3_BYTES,), dtype=torch.uint8, device=w2.device)
+    wqkv_x3 = torch.empty((WQKV_X3_BYTES,), dtype=torch.uint8, device=w2.device)
+    check(lib().gsdd_d3pm_layer_pack(ptr(w2), ptr(wproj), ptr(wqkv), ptr(lay_x3), ptr(wqkv_x3), stream_ptr(stream)))
+    return lay_x3, wqkv_x3
 
 
 def d3pm_logits(x, g, b, w, bias, out, stream=None):

@@ -182,8 +182,16 @@ typedef struct {
     const int64_t* t2;          /* device int64[M/L] timesteps                      */
     const float* wqkv; const float* bqkv; /* [192][64], [192]                       */
     float* qkv;                 /* [48][M][4] or NULL                               */
+    const void* w2_x3;          /* optional: gsdd_d3pm_layer_pack images (bf16x3 MFMA fragments) of this block's w2 + wproj */
+    const void* wqkv_x3;        /* and of the next block's wqkv.  With them the kernel streams ready-made matrix operands    */
+                                /* through LDS instead of splitting the f32 weights once per 32-row group                    */
 } gsdd_layer_desc;
 int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
+/* Pre-split w2 [64][256] + wproj [64][64] (-> layer_x3, GSDD_LAYER_X3_BYTES) and wqkv [192][64] (-> wqkv_x3,
+ * GSDD_LAYER_WQKV_X3_BYTES; both may be NULL) into the fragment images gsdd_d3pm_layer consumes; valid until the weights change. */
+#define GSDD_LAYER_X3_BYTES (40 * 3 * 1024)
+#define GSDD_LAYER_WQKV_X3_BYTES (24 * 3 * 1024)
+int gsdd_d3pm_layer_pack(const float* w2, const float* wproj, const float* wqkv, void* layer_x3, void* wqkv_x3, void* stream);
 
 /* to_logits: out[m][:] = W LayerNorm(x[m]) + bias  (nn.LayerNorm + nn.Linear, transformer_utils.py:353-356, 442);
  * x: [M][64], w: [K][64], out: [M][K] rows (the reference's (B,K,L) is a transposed view of this). */
