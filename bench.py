@@ -48,10 +48,11 @@ def build_models(args, device):
 def attention_roofline(dm, B, L, H, device, K, reps=3):
     """Dominant kernel (self-attention, head dim 4) timed live with HIP events on its launch stream, in situ: after the timed
     region `reps` more denoiser passes run eagerly on the sampler's own stream and workspace, with an event pair around every
-    full-batch attention launch (the ABI call = K/V pre-split + the attention kernel), so the kernel sees the operands, cache
+    full-batch attention launch (the ABI call; from block 1 on K and V arrive pre-split from the fused layer kernel, so this is
+    the attention kernel alone), so the kernel sees the operands, cache
     state and clocks of the real loop (a back-to-back loop of attention launches alone clocks ~6 % lower).  Algorithmic
     FLOPs = 16*L^2 per (sample, head) (QK^T 2*4 + PV 2*4 per score).  `traffic` = HBM bytes per launch from the rocprofv3
-    PMC passes committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), both kernels."""
+    PMC passes committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
     ws, (condv, Te, rep) = dm._last_ws, dm._last_run
     B2 = rep * B
     st = dm._stream
@@ -71,8 +72,8 @@ def attention_roofline(dm, B, L, H, device, K, reps=3):
     tf = flops / (ms * 1e-3) / 1e12
     traffic = None
     if (B2, L, H) == (32, 4096, 16):
-        traffic = (2 * 82019.4 + 42038.2 + 2 * 32784.4 + 131233.8) * 1024      # profiles/r1_pmc_traffic.csv
-    return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel + d3pm_attn_prep_kernel", "achieved": round(tf, 2),
+        traffic = (2 * 82019.4 + 42038.2) * 1024      # profiles/r1_pmc_traffic.csv, d3pm_attention_v4_kernel
+    return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel", "achieved": round(tf, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "ms_per_launch": round(ms, 4), "launches_timed": len(events), "flops_per_launch": flops}
 

@@ -77,6 +77,53 @@ __device__ __forceinline__ float4 philox_uniform4(uint64_t seed, uint32_t stream
     return make_float4((float)(r.x & M) * S, (float)(r.y & M) * S, (float)(r.z & M) * S, (float)(r.w & M) * S);
 }
 
+// ---------------------------------------------------------------- pre-split K / V images of the matrix-pipe attention kernel
+// (written by d3pm_attn_prep_kernel, or directly by the fused layer kernel's q|k|v epilogue)
+__device__ __forceinline__ uint32_t bf16_rn(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// x = a + b + c with a, b, c bf16 (error-free up to the last piece's rounding, < 2^-24 |x|)
+__device__ __forceinline__ void split3(float x, uint32_t& a, uint32_t& b, uint32_t& c) {
+    a = bf16_rn(x);
+    const float r = x - __uint_as_float(a << 16);
+    b = bf16_rn(r);
+    const float r2 = r - __uint_as_float(b << 16);
+    c = bf16_rn(r2);
+}
+__device__ __forceinline__ uint4 pack8(const uint32_t (&lo)[4], const uint32_t (&hi)[4]) {
+    return make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+}
+//   Kp[row][2] uint4 : pieces A=[k1|k2], B=[k3|k1] (bf16), slots swapped for (row & 15) >= 8   (row = h*M + b*L + key)
+__device__ __forceinline__ void kv_image_store_k(const float (&ks)[4], int64_t row, uint4* kp) {
+    uint32_t k1[4], k2[4], k3[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) split3(ks[d], k1[d], k2[d], k3[d]);
+    const int sw = (int)((row >> 3) & 1);
+    kp[row * 2 + sw] = pack8(k1, k2);
+    kp[row * 2 + (sw ^ 1)] = pack8(k3, k1);
+}
+//   Vp[row/32][4][16] uint4 : per 32-key pair-tile, [key group g][col j] -> 8 f16 (tile0 keys 4g+r, tile1 keys 4g+r),
+//                             cols = [v1 | v2*2^11 | v3*2^22 | 1 | 0 0 0]
+__device__ __forceinline__ void kv_image_store_v(const float (&vs)[4], int64_t row, uint4* vp) {
+    _Float16 col[16];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const _Float16 a = (_Float16)vs[d];
+        const float r1 = (vs[d] - (float)a) * 2048.f;
+        const _Float16 b2 = (_Float16)r1;
+        const float r2 = (r1 - (float)b2) * 2048.f;
+        col[d] = a; col[4 + d] = b2; col[8 + d] = (_Float16)r2;
+    }
+    col[12] = (_Float16)1.f;
+    col[13] = col[14] = col[15] = (_Float16)0.f;
+    const int64_t pair = row >> 5;
+    const int kk = (int)(row & 31), th = kk >> 4, kt = kk & 15, g = kt >> 2, r = kt & 3;
+    _Float16* dst = reinterpret_cast<_Float16*>(vp + (pair * 4 + g) * 16) + 4 * th + r;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[j * 8] = col[j];
+}
+
 // axial_attention_mfma.hip: register-resident MFMA kernels for 16-position lines; false = shape not covered
 bool axial_attention_mfma_launch(const float* qkv, int N, int T, int H, int W, int C, int n_head, int axis, float* out,
                                  hipStream_t st);

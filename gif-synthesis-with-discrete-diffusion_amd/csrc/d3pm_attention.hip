@@ -40,21 +40,6 @@ struct AttnSmem {
     uint4 ones[16];                // [1,1,1,0,0,0,0,0] bf16 at dword offsets 0 and 4 (mod 64) for the -m slots
 };
 
-__device__ __forceinline__ uint32_t bf16_rn(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-// x = a + b + c with a, b, c bf16 (error-free up to the last piece's rounding, < 2^-24 |x|)
-__device__ __forceinline__ void split3(float x, uint32_t& a, uint32_t& b, uint32_t& c) {
-    a = bf16_rn(x);
-    const float r = x - __uint_as_float(a << 16);
-    b = bf16_rn(r);
-    const float r2 = r - __uint_as_float(b << 16);
-    c = bf16_rn(r2);
-}
-__device__ __forceinline__ uint4 pack8(const uint32_t (&lo)[4], const uint32_t (&hi)[4]) {
-    return make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-}
 __device__ __forceinline__ bf16x8 as_frag(uint4 u) {
     union { uint4 u; bf16x8 v; } c;
     c.u = u;
@@ -343,30 +328,9 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
     if (row >= rows) return;
     const float4 rk = *reinterpret_cast<const float4*>(k + row * 4);
     const float4 rv = *reinterpret_cast<const float4*>(v + row * 4);
-    const float ks[4] = {rk.x, rk.y, rk.z, rk.w};
-    uint32_t k1[4], k2[4], k3[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) split3(ks[d], k1[d], k2[d], k3[d]);
-    const int sw = (int)((row >> 3) & 1);
-    kp[row * 2 + sw] = pack8(k1, k2);
-    kp[row * 2 + (sw ^ 1)] = pack8(k3, k1);
-    const float vs[4] = {rv.x, rv.y, rv.z, rv.w};
-    _Float16 col[16];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const _Float16 a = (_Float16)vs[d];
-        const float r1 = (vs[d] - (float)a) * 2048.f;
-        const _Float16 b2 = (_Float16)r1;
-        const float r2 = (r1 - (float)b2) * 2048.f;
-        col[d] = a; col[4 + d] = b2; col[8 + d] = (_Float16)r2;
-    }
-    col[12] = (_Float16)1.f;
-    col[13] = col[14] = col[15] = (_Float16)0.f;
-    const int64_t pair = row >> 5;
-    const int kk = (int)(row & 31), th = kk >> 4, kt = kk & 15, g = kt >> 2, r = kt & 3;
-    _Float16* dst = reinterpret_cast<_Float16*>(vp + (pair * 4 + g) * 16) + 4 * th + r;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dst[j * 8] = col[j];
+    const float ks[4] = {rk.x, rk.y, rk.z, rk.w}, vs[4] = {rv.x, rv.y, rv.z, rv.w};
+    kv_image_store_k(ks, row, kp);
+    kv_image_store_v(vs, row, vp);
 }
 
 template <int KC4>
@@ -587,9 +551,12 @@ int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, i
 
 extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
                                    void* workspace, int64_t workspace_bytes, void* stream) {
-    GSDD_CHECK_ARG(q && k && v && out, "null pointer");
+    GSDD_CHECK_ARG(q && out && ((k == nullptr) == (v == nullptr)), "null pointer");
     GSDD_CHECK_ARG(B > 0 && H > 0 && L > 0, "bad sizes");
     GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
+    const bool premade = k == nullptr;        // the workspace already holds the K / V images (gsdd_d3pm_layer wrote them)
+    static const bool force_v3e = getenv("GSDD_ATTN_V3") != nullptr;
+    GSDD_CHECK_ARG(!premade || (L % 32 == 0 && workspace != nullptr && !force_v3e), "k = v = NULL needs the matrix-pipe kernel's images in the workspace");
     if (L % 16 != 0) return gsdd_attention_valu(q, k, v, B, L, H, out, nullptr, stream);     // ragged lengths: VALU kernel
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
     static const bool force_v3 = getenv("GSDD_ATTN_V3") != nullptr;    // A/B switch: exact-f32 P.V (mfma 4x4x1) variant
@@ -599,8 +566,10 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
         const int64_t rows = (int64_t)B * L * H;
         uint4* kp = reinterpret_cast<uint4*>(workspace);
         uint4* vp = kp + rows * 2;
-        hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
-        GSDD_CHECK_LAUNCH();
+        if (!premade) {
+            hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
+            GSDD_CHECK_LAUNCH();
+        }
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
         if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
         else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);

@@ -41,6 +41,7 @@ struct LayerArgs {
     float* qkv;                // [48][M][4]
     const uint4* w2_x3;        // optional fragment images (gsdd_d3pm_layer_pack)
     const uint4* wqkv_x3;
+    uint4* kimg; uint4* vimg;  // optional: the next block's attention images (k, v go there instead of qkv rows)
 };
 
 // GELU2 (transformer_utils.py:115-119): v * sigmoid(1.702 v) = v / (1 + 2^(-1.702 log2(e) v)).
@@ -884,7 +885,18 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
                     const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
                     o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
                 }
-                if (full) {
+                if (c > 0 && a.kimg != nullptr) {
+                    // k / v of head hd = 8 t + 2 g + h as the attention kernel's pre-split images (row = hd * M + m)
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int hd = 8 * (q >> 2) + 2 * (q & 3) + h;
+                            const float vals[4] = {o[q].x, o[q].y, o[q].z, o[q].w};
+                            if (c == 1) kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
+                            else kv_image_store_v(vals, (int64_t)hd * a.M + m, a.vimg);
+                        }
+                    }
+                } else if (full) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
@@ -1069,6 +1081,13 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
         attr_done = true;
     }
     a.w2_x3 = reinterpret_cast<const uint4*>(d->w2_x3); a.wqkv_x3 = reinterpret_cast<const uint4*>(d->wqkv_x3);
+    a.kimg = a.vimg = nullptr;
+    if (has_qkv && d->kv_img != nullptr) {
+        GSDD_CHECK_ARG(d->w2_x3 != nullptr && d->wqkv_x3 != nullptr && d->L % 32 == 0 && getenv("GSDD_LAYER") == nullptr,
+                       "kv_img needs the packed-weight kernel (both fragment images) and L % 32 == 0");
+        a.kimg = reinterpret_cast<uint4*>(d->kv_img);
+        a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
+    }
     // GSDD_LAYER=f32 | x3 | x3p forces a variant (A/B); default: fragment images when the caller packed them, else on-the-fly splits
     static const char* force = getenv("GSDD_LAYER");
     const bool have_img = d->w2_x3 != nullptr && (!has_qkv || d->wqkv_x3 != nullptr);

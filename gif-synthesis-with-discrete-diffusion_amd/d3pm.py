@@ -7,6 +7,7 @@ reference's names; the sampling loop runs as one captured
 step, replayed diffusion_step times with the timestep and the Philox stream id living in device memory.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -192,6 +193,11 @@ class Text2ImageTransformer(nn.Module):
             ops.linear(x[:M1] if share0 else x, layers[0]["wqkv"], ws["qkv0"] if share0 else qkv, bias=layers[0]["bqkv"],
                        ln=(stats, layers[0]["ada1"].view(-1), layers[0]["ada1"].view(-1)[D:], t2, 2 * D),
                        rows_per_batch=L, out_mode=2, stream=stream)
+            # From block 1 on, the fused layer kernel writes k and v straight into the attention workspace as the matrix-pipe
+            # kernel's pre-split images (no f32 k|v rows, no pre-split pass)
+            attn_ws = ws.get("attn")
+            img = (attn_ws is not None and L % 32 == 0 and all("wqkv_x3" in l and "w2_x3" in l for l in layers)
+                   and not any(os.environ.get(e) for e in ("GSDD_LAYER", "GSDD_ATTN_V3")))
             for li, lay in enumerate(layers):
                 if li == 0 and share0:
                     q0 = ws["qkv0"]
@@ -204,11 +210,14 @@ class Text2ImageTransformer(nn.Module):
                     if ev is not None:
                         ev.append((ops.Event(), ops.Event()))
                         ev[-1][0].record(stream)
-                    ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), stream=stream)
+                    if img and li > 0:
+                        ops.d3pm_attention(qkv[0:H], None, None, B2, L, H, y, ws=attn_ws, stream=stream)
+                    else:
+                        ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=attn_ws, stream=stream)
                     if ev is not None:
                         ev[-1][1].record(stream)
                 nxt = layers[li + 1] if li + 1 < len(layers) else None
-                ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, stream=stream)
+                ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, kv_img=attn_ws if img else None, stream=stream)
         else:
             self._run_blocks_unfused(layers, condv, Te, t2, ws, B2, L, stream)
         if D == 64 and p["wl"].shape[0] % 4 == 0:

@@ -169,7 +169,7 @@ def d3pm_attention(q, k, v, B, L, H, out, ws=None, stream=None):
     return out
 
 
-def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, stream=None):
+def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, stream=None):
     """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given)."""
     d = LayerDesc()
     d.y, d.x, d.M, d.L, d.n_embd, d.hidden = ptr(y), ptr(x), x.shape[0], L, x.shape[1], lay["w1"].shape[0]
@@ -180,6 +180,7 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, stream=None
     if nxt is not None:
         d.ada, d.t2, d.wqkv, d.bqkv, d.qkv = ptr(nxt["ada1"]), ptr(t2), ptr(nxt["wqkv"]), ptr(nxt["bqkv"]), ptr(qkv)
         d.wqkv_x3 = ptr(nxt.get("wqkv_x3"))
+        d.kv_img = ptr(kv_img)
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
 
 

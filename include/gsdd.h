@@ -159,6 +159,7 @@ int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const floa
 /* workspace: gsdd_d3pm_attention_workspace_bytes(B,L,H) bytes of scratch for the pre-split K/V images of the
  * matrix-pipe kernel; NULL selects the workspace-free kernel (exact-f32 P.V on v_mfma_f32_4x4x1). */
 int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H);
+/* k = v = NULL: the workspace already holds the K / V images (written by gsdd_d3pm_layer through kv_img). */
 int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
                         float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
@@ -185,6 +186,9 @@ typedef struct {
     const void* w2_x3;          /* optional: gsdd_d3pm_layer_pack images (bf16x3 MFMA fragments) of this block's w2 + wproj */
     const void* wqkv_x3;        /* and of the next block's wqkv.  With them the kernel streams ready-made matrix operands    */
                                 /* through LDS instead of splitting the f32 weights once per 32-row group                    */
+    void* kv_img;               /* optional (needs both images above and L % 32 == 0): the attention workspace of the next     */
+                                /* block.  k and v are then written there as the matrix-pipe kernel's pre-split images instead */
+                                /* of f32 rows of qkv, and gsdd_d3pm_attention is called with k = v = NULL (no prep pass)      */
 } gsdd_layer_desc;
 int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
 /* Pre-split w2 [64][256] + wproj [64][64] (-> layer_x3, GSDD_LAYER_X3_BYTES) and wqkv [192][64] (-> wqkv_x3,
