@@ -96,12 +96,20 @@ __device__ __forceinline__ uint4 pack8(const uint32_t (&lo)[4], const uint32_t (
 }
 //   Kp[row][2] uint4 : pieces A=[k1|k2], B=[k3|k1] (bf16), slots swapped for (row & 15) >= 8   (row = h*M + b*L + key)
 __device__ __forceinline__ void kv_image_store_k(const float (&ks)[4], int64_t row, uint4* kp) {
-    uint32_t k1[4], k2[4], k3[4];
+    // the same round-to-nearest pieces as split3, through the hardware conversion (v_cvt_pk_bf16_f32) instead of integer rounding
+    typedef __bf16 kbf16x8 __attribute__((ext_vector_type(8)));
+    kbf16x8 a, b;                                   // a = [k1 | k2], b = [k3 | k1]
 #pragma unroll
-    for (int d = 0; d < 4; ++d) split3(ks[d], k1[d], k2[d], k3[d]);
+    for (int d = 0; d < 4; ++d) {
+        const __bf16 p1 = (__bf16)ks[d];
+        const float r1 = ks[d] - (float)p1;
+        const __bf16 p2 = (__bf16)r1;
+        const __bf16 p3 = (__bf16)(r1 - (float)p2);
+        a[d] = p1; a[4 + d] = p2; b[d] = p3; b[4 + d] = p1;
+    }
     const int sw = (int)((row >> 3) & 1);
-    kp[row * 2 + sw] = pack8(k1, k2);
-    kp[row * 2 + (sw ^ 1)] = pack8(k3, k1);
+    kp[row * 2 + sw] = __builtin_bit_cast(uint4, a);
+    kp[row * 2 + (sw ^ 1)] = __builtin_bit_cast(uint4, b);
 }
 //   Vp[row/32][4][16] uint4 : per 32-key pair-tile, [key group g][col j] -> 8 f16 (tile0 keys 4g+r, tile1 keys 4g+r),
 //                             cols = [v1 | v2*2^11 | v3*2^22 | 1 | 0 0 0]

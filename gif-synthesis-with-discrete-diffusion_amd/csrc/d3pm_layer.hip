@@ -871,12 +871,49 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
 #pragma unroll 1
             for (int c = 0; c < 3; ++c) {
                 zero2(acc);
+                // The V image wants eight *rows* of one column in a lane (below), so for it the product is taken the other way
+                // round (activations as the A operand): acc[nt][r] = v[row 8 (r >> 2) + 4 h + (r & 3)][feature 32 nt + li].
+                const bool v_img = c == 2 && a.vimg != nullptr;                         // wave-uniform
 #pragma unroll
                 for (int ts = 0; ts < 8; ++ts) {
                     const int fn = 8 * c + ts + 2;                 // (wraps to fragment 0 / 1 after the last block: harmless)
                     const P3 wq2 = load_frag3(img_qkv, fn < 24 ? fn : fn - 24, lane);
-                    mma6(wq0, bp[ts >> 1], acc[ts & 1]);
+                    if (v_img) mma6(bp[ts >> 1], wq0, acc[ts & 1]);
+                    else mma6(wq0, bp[ts >> 1], acc[ts & 1]);
                     wq0 = wq1; wq1 = wq2;
+                }
+                if (v_img) {
+                    // lane (li, h): head hd = 8 nt + (li >> 2), dim d = li & 3.  Accumulator registers 4 g2 + e and 4 (g2 + 2) + e
+                    // (e = 0..3) are rows 4 g + e of the group's two 16-key tiles for key group g = 2 g2 + h: the eight f16 of
+                    // image entry (pair-tile, g, column) — three entries for the three pieces of v, and lane d also writes the
+                    // constant column 12 + d (1, 0, 0, 0).  (The group is one 32-key pair-tile of every head: L % 32 == 0.)
+                    const int d = li & 3;
+                    const uint32_t cst = d == 0 ? 0x3C003C00u : 0u;                       // f16 1.0 | 1.0
+                    const int64_t m0 = grp * 32;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int hd = 8 * nt + (li >> 2);
+                        const float bv = par[PAR_BQKV + 128 + 32 * nt + li];
+                        uint4* dst = a.vimg + (((int64_t)hd * a.M + m0) >> 5) * 64;
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            _Float16 p1[8], p2[8], p3[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = acc[nt][4 * g2 + (e & 3) + 8 * (e >> 2)] + bv;
+                                const _Float16 a1 = (_Float16)v;
+                                const float r1 = (v - (float)a1) * 2048.f;
+                                const _Float16 a2 = (_Float16)r1;
+                                p1[e] = a1; p2[e] = a2; p3[e] = (_Float16)((r1 - (float)a2) * 2048.f);
+                            }
+                            uint4* e0 = dst + (2 * g2 + h) * 16;
+                            e0[d] = __builtin_bit_cast(uint4, p1);
+                            e0[4 + d] = __builtin_bit_cast(uint4, p2);
+                            e0[8 + d] = __builtin_bit_cast(uint4, p3);
+                            e0[12 + d] = make_uint4(cst, cst, cst, cst);
+                        }
+                    }
+                    continue;
                 }
                 float4 o[8];
 #pragma unroll
@@ -885,15 +922,14 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
                     const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
                     o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
                 }
-                if (c > 0 && a.kimg != nullptr) {
-                    // k / v of head hd = 8 t + 2 g + h as the attention kernel's pre-split images (row = hd * M + m)
+                if (c == 1 && a.kimg != nullptr) {
+                    // k of head hd = 8 t + 2 g + h as the attention kernel's pre-split image (row = hd * M + m): two 16-byte stores
                     if (valid) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const int hd = 8 * (q >> 2) + 2 * (q & 3) + h;
                             const float vals[4] = {o[q].x, o[q].y, o[q].z, o[q].w};
-                            if (c == 1) kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
-                            else kv_image_store_v(vals, (int64_t)hd * a.M + m, a.vimg);
+                            kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
                         }
                     }
                 } else if (full) {
