@@ -53,7 +53,7 @@ def attention_roofline(dm, B, L, H, device, K, reps=3):
     state and clocks of the real loop (a back-to-back loop of attention launches alone clocks ~6 % lower).  Algorithmic
     FLOPs = 16*L^2 per (sample, head) (QK^T 2*4 + PV 2*4 per score).  `traffic` = HBM bytes per launch from the rocprofv3
     PMC passes committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
-    ws, (condv, Te, rep) = dm._last_ws, dm._last_run
+    ws, (condv, Te, rep, B) = dm._last_ws, dm._last_run            # one lane of the sampler (B = its sub-batch)
     B2 = rep * B
     st = dm._stream
     tok = torch.randint(0, K, (B, L), device=device)
@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches of the sampler (separate HIP streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,6 +142,7 @@ def main():
     cond = torch.randn(B, 1, 512, generator=g).to(device)          # general conditioning (not the zeroed case)
     cf_cond = torch.zeros(B, 1, 512, device=device)
     dm.set_noise(1234, 0, row_offset=rank * B)
+    dm.sample_lanes = args.lanes
 
     def one_pass():
         out = dm.sample(texts, None, cond, cf_cond, content_token=None, filter_ratio=0, use_graph=not args.no_graph)

@@ -133,3 +133,22 @@ def test_full_size_sampling_properties(G):
     dm.set_noise(5, row_offset=1)          # second sample alone, keyed as global row 1
     c = dm.sample(["x"], None, cond[1:], cf[1:], filter_ratio=0, use_graph=True)["content_token"].cpu()
     assert torch.equal(c[0], a[1])
+
+
+def test_sampler_lanes_give_the_same_tokens(G):
+    """Two concurrent sub-batches on separate streams (sample(..., lanes=2)) must reproduce the single-lane tokens: each
+    clip's chain depends only on its own rows of the noise stream."""
+    torch.manual_seed(3)
+    d = G.DalleMaskImageEmbedding(num_embed=256, spatial_size=[16, 16], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=256, block_activate="GELU2",
+                                 content_spatial_size=[16, 16], diffusion_step=20)
+    dm = G.DiffusionTransformer(transformer=tr, diffusion_step=20, alpha_init_type="alpha1", guidance_scale=2,
+                                content_seq_len=256).cuda().eval()
+    B = 8
+    cond, cf = torch.randn(B, 1, 512).cuda(), torch.zeros(B, 1, 512).cuda()
+    outs = []
+    for lanes in (1, 2):
+        dm.set_noise(99, 0, row_offset=5)
+        outs.append(dm.sample(["a"] * B, None, cond, cf, filter_ratio=0, lanes=lanes)["content_token"].cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] < 256).all()
