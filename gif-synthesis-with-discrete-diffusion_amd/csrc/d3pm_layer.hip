@@ -684,7 +684,8 @@ __device__ __forceinline__ void gemm_lds_img(const uint4* img, int f0, int lane,
     }
 }
 
-template <bool HAS_QKV>
+// QKV_ONLY: only the next-block stage (AdaLN + q|k|v of x as it is): block 0 of the denoiser, whose input is the embedding
+template <bool HAS_QKV, bool QKV_ONLY = false>
 __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     uint4* iw1 = reinterpret_cast<uint4*>(lds);              // 32 fragments
@@ -697,15 +698,18 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
     const uint4* img_qkv = a.wqkv_x3;                        // 24 fragments
 
     // ---- W1 is split by the workgroup once; Wproj's fragments are copied from the layer image
-    for (int u = tid; u < 32 * 64; u += 512) {
-        const int f = u >> 6, l = u & 63, fl = l & 31, fh = l >> 5;
-        const int nt = f & 1, q = (f >> 1) & 3, c = f >> 3;
-        store_frag(iw1, f, l, split8_w(a.w1 + (int64_t)(64 * c + 32 * nt + fl) * D + 16 * q + 4 * fh));
+    if (!QKV_ONLY) {
+        for (int u = tid; u < 32 * 64; u += 512) {
+            const int f = u >> 6, l = u & 63, fl = l & 31, fh = l >> 5;
+            const int nt = f & 1, q = (f >> 1) & 3, c = f >> 3;
+            store_frag(iw1, f, l, split8_w(a.w1 + (int64_t)(64 * c + 32 * nt + fl) * D + 16 * q + 4 * fh));
+        }
+        for (int u = tid; u < IMG_BLOCK_U4; u += 512) iwp[u] = img_w2[4 * IMG_BLOCK_U4 + u];
     }
-    for (int u = tid; u < IMG_BLOCK_U4; u += 512) iwp[u] = img_w2[4 * IMG_BLOCK_U4 + u];
     for (int i = tid; i < PAR_N; i += 512) {
         float v;
-        if (i < PAR_G2) v = a.bproj[i];
+        if (QKV_ONLY) v = i >= PAR_BQKV ? a.bqkv[i - PAR_BQKV] : 0.f;
+        else if (i < PAR_G2) v = a.bproj[i];
         else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2];
         else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN];
         else if (i < PAR_B2) v = a.b1[i - PAR_B1];
@@ -738,6 +742,10 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
         float act[32], x1[32];
         f32x16 acc[2];
         P3 bp[4];
+        float mean, rstd;
+        if (QKV_ONLY) {
+            load_frag(a.x + mc * D, h, x1);
+        } else {
         // W2 fragments come from L2: tile 0 of a k-step is requested during the previous k-step, tile 1 at the start of its own
         // (deeper prefetch spills: registers, not L2 latency, are the scarce resource here); the first one is in flight during
         // proj / LN / W1
@@ -764,7 +772,6 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
                 x1[16 * t + r + 3] += (acc[t][r + 3] + bpj.w) + cv.w;
             }
         // ---- h = LN2(x1) * gamma + beta
-        float mean, rstd;
         row_norm(x1, mean, rstd);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -842,6 +849,7 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
             for (int q = 0; q < 8; ++q)
                 *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
                     make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        }
         }
         if (HAS_QKV) {
             // Wqkv fragments come from L2 two tile-steps ahead of their use; the first two are requested before the AdaLN arithmetic
@@ -1094,7 +1102,8 @@ using namespace gsdd;
 
 extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     GSDD_CHECK_ARG(d != nullptr, "null descriptor");
-    GSDD_CHECK_ARG(d->y && d->x && d->wproj && d->bproj && d->ln2_g && d->ln2_b && d->w1 && d->b1 && d->w2 && d->b2,
+    const bool qkv_only = d->y == nullptr;                     // next-block stage only (block 0): needs the packed kernel
+    GSDD_CHECK_ARG(d->x && (qkv_only || (d->y && d->wproj && d->bproj && d->ln2_g && d->ln2_b && d->w1 && d->b1 && d->w2 && d->b2)),
                    "null pointer");
     GSDD_CHECK_ARG(d->M > 0 && d->M < (1ll << 31) && d->L > 0, "bad sizes");
     GSDD_CHECK_ARG(d->n_embd == 64 && d->hidden == 256, "kernel is specialised for n_embd 64, hidden 256");
@@ -1119,7 +1128,7 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     a.w2_x3 = reinterpret_cast<const uint4*>(d->w2_x3); a.wqkv_x3 = reinterpret_cast<const uint4*>(d->wqkv_x3);
     a.kimg = a.vimg = nullptr;
     if (has_qkv && d->kv_img != nullptr) {
-        GSDD_CHECK_ARG(d->w2_x3 != nullptr && d->wqkv_x3 != nullptr && d->L % 32 == 0 && getenv("GSDD_LAYER") == nullptr,
+        GSDD_CHECK_ARG((d->y == nullptr || d->w2_x3 != nullptr) && d->wqkv_x3 != nullptr && d->L % 32 == 0 && getenv("GSDD_LAYER") == nullptr,
                        "kv_img needs the packed-weight kernel (both fragment images) and L % 32 == 0");
         a.kimg = reinterpret_cast<uint4*>(d->kv_img);
         a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
@@ -1127,7 +1136,8 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     // GSDD_LAYER=f32 | x3 | x3p forces a variant (A/B); default: fragment images when the caller packed them, else on-the-fly splits
     static const char* force = getenv("GSDD_LAYER");
     const bool have_img = d->w2_x3 != nullptr && (!has_qkv || d->wqkv_x3 != nullptr);
-    const int variant = force == nullptr ? (have_img ? 2 : 1) : (force[0] == 'f' ? 0 : ((force[2] == 'p' && have_img) ? 2 : 1));
+    const int variant = qkv_only ? 2 : force == nullptr ? (have_img ? 2 : 1) : (force[0] == 'f' ? 0 : ((force[2] == 'p' && have_img) ? 2 : 1));
+    GSDD_CHECK_ARG(!qkv_only || (has_qkv && d->wqkv_x3 != nullptr), "y = NULL (q|k|v stage only) needs qkv and the wqkv image");
     if (variant == 0) {
         if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
@@ -1140,9 +1150,11 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
         if (!attr_p) {
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
             attr_p = true;
         }
-        if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3p_kernel<true>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
+        if (qkv_only) hipLaunchKernelGGL((d3pm_layer_x3p_kernel<true, true>), dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
+        else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3p_kernel<true>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(d3pm_layer_x3p_kernel<false>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
     }
     GSDD_CHECK_LAUNCH();

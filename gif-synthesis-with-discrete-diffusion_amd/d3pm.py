@@ -189,19 +189,25 @@ class Text2ImageTransformer(nn.Module):
             # block 0's q|k|v and self-attention output are identical in every copy: computed once, then copied.
             M1 = B * L
             share0 = rep > 1 and "qkv0" in ws
-            ops.row_stats(x[:M1] if share0 else x, stats, stream=stream)
-            ops.linear(x[:M1] if share0 else x, layers[0]["wqkv"], ws["qkv0"] if share0 else qkv, bias=layers[0]["bqkv"],
-                       ln=(stats, layers[0]["ada1"].view(-1), layers[0]["ada1"].view(-1)[D:], t2, 2 * D),
-                       rows_per_batch=L, out_mode=2, stream=stream)
-            # From block 1 on, the fused layer kernel writes k and v straight into the attention workspace as the matrix-pipe
-            # kernel's pre-split images (no f32 k|v rows, no pre-split pass)
+            # The fused layer kernel writes k and v straight into the attention workspace as the matrix-pipe kernel's pre-split
+            # images (no f32 k|v rows, no pre-split pass); block 0 runs its q|k|v stage alone on the embedding
             attn_ws = ws.get("attn")
             img = (attn_ws is not None and L % 32 == 0 and all("wqkv_x3" in l and "w2_x3" in l for l in layers)
                    and not any(os.environ.get(e) for e in ("GSDD_LAYER", "GSDD_ATTN_V3")))
+            x0, q0 = (x[:M1], ws["qkv0"]) if share0 else (x, qkv)
+            if img:
+                ops.d3pm_layer(None, x0, L, None, nxt=layers[0], t2=t2, qkv=q0, kv_img=attn_ws, stream=stream)
+            else:
+                ops.row_stats(x0, stats, stream=stream)
+                ops.linear(x0, layers[0]["wqkv"], q0, bias=layers[0]["bqkv"],
+                           ln=(stats, layers[0]["ada1"].view(-1), layers[0]["ada1"].view(-1)[D:], t2, 2 * D),
+                           rows_per_batch=L, out_mode=2, stream=stream)
             for li, lay in enumerate(layers):
                 if li == 0 and share0:
-                    q0 = ws["qkv0"]
-                    ops.d3pm_attention(q0[0:H], q0[H:2 * H], q0[2 * H:3 * H], B, L, H, y, ws=ws.get("attn"), stream=stream)
+                    if img:
+                        ops.d3pm_attention(q0[0:H], None, None, B, L, H, y, ws=attn_ws, stream=stream)
+                    else:
+                        ops.d3pm_attention(q0[0:H], q0[H:2 * H], q0[2 * H:3 * H], B, L, H, y, ws=attn_ws, stream=stream)
                     with torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else contextlib.nullcontext():
                         for r in range(1, rep):
                             y[r * M1:(r + 1) * M1].copy_(y[:M1])
@@ -210,7 +216,7 @@ class Text2ImageTransformer(nn.Module):
                     if ev is not None:
                         ev.append((ops.Event(), ops.Event()))
                         ev[-1][0].record(stream)
-                    if img and li > 0:
+                    if img:
                         ops.d3pm_attention(qkv[0:H], None, None, B2, L, H, y, ws=attn_ws, stream=stream)
                     else:
                         ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=attn_ws, stream=stream)

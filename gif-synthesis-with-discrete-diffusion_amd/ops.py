@@ -170,13 +170,16 @@ def d3pm_attention(q, k, v, B, L, H, out, ws=None, stream=None):
 
 
 def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, stream=None):
-    """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given)."""
+    """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given).
+    y = lay = None: only the next-block stage on x as it is (block 0, whose input is the embedding)."""
     d = LayerDesc()
-    d.y, d.x, d.M, d.L, d.n_embd, d.hidden = ptr(y), ptr(x), x.shape[0], L, x.shape[1], lay["w1"].shape[0]
+    d.y, d.x, d.M, d.L, d.n_embd, d.hidden = ptr(y), ptr(x), x.shape[0], L, x.shape[1], 256
     d.cvec = ptr(cvec)
-    d.wproj, d.bproj, d.ln2_g, d.ln2_b = ptr(lay["wproj"]), ptr(lay["bproj"]), ptr(lay["g2"]), ptr(lay["b2"])
-    d.w1, d.b1, d.w2, d.b2 = ptr(lay["w1"]), ptr(lay["bb1"]), ptr(lay["w2"]), ptr(lay["bb2"])
-    d.w2_x3 = ptr(lay.get("w2_x3"))
+    if lay is not None:
+        d.hidden = lay["w1"].shape[0]
+        d.wproj, d.bproj, d.ln2_g, d.ln2_b = ptr(lay["wproj"]), ptr(lay["bproj"]), ptr(lay["g2"]), ptr(lay["b2"])
+        d.w1, d.b1, d.w2, d.b2 = ptr(lay["w1"]), ptr(lay["bb1"]), ptr(lay["w2"]), ptr(lay["bb2"])
+        d.w2_x3 = ptr(lay.get("w2_x3"))
     if nxt is not None:
         d.ada, d.t2, d.wqkv, d.bqkv, d.qkv = ptr(nxt["ada1"]), ptr(t2), ptr(nxt["wqkv"]), ptr(nxt["bqkv"]), ptr(qkv)
         d.wqkv_x3 = ptr(nxt.get("wqkv_x3"))
