@@ -364,3 +364,46 @@ def test_vqvae_train_forward_matches_reference(G):
     with torch.no_grad():
         want = ov.decode(torch.zeros((1, 4, 4, 4), dtype=torch.long), after, cfg)
     torch.testing.assert_close(rec.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+def test_fused_layer_variants_agree(G):
+    """gsdd_d3pm_layer with the pre-split weight images (default when Text2ImageTransformer packs them), without them
+    (weights split on the fly), and writing k/v as attention images instead of f32 rows: same block output; the image path is
+    checked through the attention kernel that consumes it."""
+    torch.manual_seed(11)
+    B2, L, H, Dm = 4, 64, 16, 64
+    d = G.DalleMaskImageEmbedding(num_embed=33, spatial_size=[8, 8], embed_dim=Dm)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=Dm, n_head=H, content_seq_len=L, block_activate="GELU2",
+                                 content_spatial_size=[8, 8], diffusion_step=10).cuda()
+    with torch.no_grad():
+        for p_ in tr.parameters():
+            p_.mul_(8.0)                      # N(0, 0.02) init would make every block nearly the identity
+    lay0, lay1 = tr.packed()["layers"]
+    M = B2 * L
+    y = torch.randn(M, Dm, device="cuda")
+    x_in = torch.randn(M, Dm, device="cuda")
+    cv = torch.randn(B2, Dm, device="cuda")
+    t2 = torch.tensor([0, 3, 9, 5], dtype=torch.int64, device="cuda")
+    plain0 = {k: v for k, v in lay0.items() if not k.endswith("_x3")}
+    plain1 = {k: v for k, v in lay1.items() if not k.endswith("_x3")}
+    outs = []
+    for l0, l1 in ((lay0, lay1), (plain0, plain1)):
+        x = x_in.clone()
+        qkv = torch.zeros(3 * H, M, 4, device="cuda")
+        G.ops.d3pm_layer(y, x, L, l0, cvec=cv, nxt=l1, t2=t2, qkv=qkv)
+        outs.append((x, qkv))
+    torch.testing.assert_close(outs[0][0], outs[1][0], atol=2e-5, rtol=0)
+    torch.testing.assert_close(outs[0][1], outs[1][1], atol=2e-5, rtol=0)
+    # k, v as images: attention on (q rows, images) == attention on the f32 q, k, v rows
+    ws = G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda"))
+    x = x_in.clone()
+    qkv2 = torch.zeros(3 * H, M, 4, device="cuda")
+    G.ops.d3pm_layer(y, x, L, lay0, cvec=cv, nxt=lay1, t2=t2, qkv=qkv2, kv_img=ws)
+    torch.testing.assert_close(x, outs[0][0], atol=0, rtol=0)
+    assert torch.equal(qkv2[:H], outs[0][1][:H]) and not qkv2[H:].any()          # q rows written, k/v rows untouched
+    a_img = torch.empty(M, Dm, device="cuda")
+    a_ref = torch.empty(M, Dm, device="cuda")
+    G.ops.d3pm_attention(qkv2[:H], None, None, B2, L, H, a_img, ws=ws)
+    q, k, v = outs[0][1][:H], outs[0][1][H:2 * H], outs[0][1][2 * H:]
+    G.ops.d3pm_attention(q, k, v, B2, L, H, a_ref, ws=G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda")))
+    torch.testing.assert_close(a_img, a_ref, atol=1e-6, rtol=0)
