@@ -407,3 +407,25 @@ def test_fused_layer_variants_agree(G):
     q, k, v = outs[0][1][:H], outs[0][1][H:2 * H], outs[0][1][2 * H:]
     G.ops.d3pm_attention(q, k, v, B2, L, H, a_ref, ws=G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda")))
     torch.testing.assert_close(a_img, a_ref, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("L,spatial", [(48, [8, 8]), (96, [16, 8])])
+def test_denoiser_ragged_lengths_match_oracle(G, L, spatial):
+    """L % 32 != 0 (VALU attention, f32 q|k|v rows, generic block-0 GEMM) and L % 32 == 0 with the image path: both against the
+    CPU oracle's denoiser on the same random weights."""
+    from oracle import d3pm as od
+    torch.manual_seed(L)
+    K, B = 32, 3
+    d = G.DalleMaskImageEmbedding(num_embed=K, spatial_size=spatial, embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=3, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                 content_spatial_size=spatial, diffusion_step=10)
+    with torch.no_grad():
+        for p_ in tr.parameters():
+            p_.mul_(6.0)
+    sd = {"transformer." + k: v.detach().clone() for k, v in tr.state_dict().items()}
+    tok = torch.randint(0, K + 1, (B, L))
+    cond = torch.randn(B, 1, 512)
+    t = torch.tensor([0, 4, 9])
+    want = od.denoiser(tok, cond, t, sd)
+    got = tr.cuda()(tok.cuda(), cond.cuda(), t.cuda())
+    torch.testing.assert_close(got.cpu(), want, atol=LOGIT_TOL, rtol=0)
