@@ -672,12 +672,14 @@ __global__ __launch_bounds__(256) void layer_pack_kernel(const float* w2, const 
 
 // acc[nt] += (fragments f0 .. f0+7 of an LDS image) x the four k-steps of bp; the next fragment's three ds_read_b128 are
 // issued before the current fragment's six MFMAs
+template <bool SWAP = false>   // SWAP: activations as the A operand (result: row in registers, feature on the lane)
 __device__ __forceinline__ void gemm_lds_img(const uint4* img, int f0, int lane, const P3 (&bp)[4], f32x16 (&acc)[2]) {
     P3 cur = load_frag3(img, f0, lane);
 #pragma unroll
     for (int ts = 0; ts < 8; ++ts) {
         const P3 nxt = load_frag3(img, f0 + (ts < 7 ? ts + 1 : 0), lane);
-        mma6(cur, bp[ts >> 1], acc[ts & 1]);
+        if (SWAP) mma6(bp[ts >> 1], cur, acc[ts & 1]);
+        else mma6(cur, bp[ts >> 1], acc[ts & 1]);
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // the three reads first,
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);     // then the six MFMAs
         cur = nxt;
@@ -705,6 +707,8 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
             store_frag(iw1, f, l, split8_w(a.w1 + (int64_t)(64 * c + 32 * nt + fl) * D + 16 * q + 4 * fh));
         }
         for (int u = tid; u < IMG_BLOCK_U4; u += 512) iwp[u] = img_w2[4 * IMG_BLOCK_U4 + u];
+    } else {
+        for (int u = tid; u < 3 * IMG_BLOCK_U4; u += 512) iw1[u] = img_qkv[u];     // the whole Wqkv image (72 KB) is LDS-resident
     }
     for (int i = tid; i < PAR_N; i += 512) {
         float v;
@@ -853,7 +857,8 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
         }
         if (HAS_QKV) {
             // Wqkv fragments come from L2 two tile-steps ahead of their use; the first two are requested before the AdaLN arithmetic
-            P3 wq0 = load_frag3(img_qkv, 0, lane), wq1 = load_frag3(img_qkv, 1, lane);
+            P3 wq0, wq1;
+            if (!QKV_ONLY) { wq0 = load_frag3(img_qkv, 0, lane); wq1 = load_frag3(img_qkv, 1, lane); }
             row_norm(x1, mean, rstd);
             const float* tab = a.ada + a.t2[b] * (2 * D);
 #pragma unroll
@@ -882,13 +887,18 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
                 // The V image wants eight *rows* of one column in a lane (below), so for it the product is taken the other way
                 // round (activations as the A operand): acc[nt][r] = v[row 8 (r >> 2) + 4 h + (r & 3)][feature 32 nt + li].
                 const bool v_img = c == 2 && a.vimg != nullptr;                         // wave-uniform
+                if (QKV_ONLY) {
+                    if (v_img) gemm_lds_img<true>(iw1, 8 * c, lane, bp, acc);
+                    else gemm_lds_img<false>(iw1, 8 * c, lane, bp, acc);
+                } else {
 #pragma unroll
-                for (int ts = 0; ts < 8; ++ts) {
-                    const int fn = 8 * c + ts + 2;                 // (wraps to fragment 0 / 1 after the last block: harmless)
-                    const P3 wq2 = load_frag3(img_qkv, fn < 24 ? fn : fn - 24, lane);
-                    if (v_img) mma6(bp[ts >> 1], wq0, acc[ts & 1]);
-                    else mma6(wq0, bp[ts >> 1], acc[ts & 1]);
-                    wq0 = wq1; wq1 = wq2;
+                    for (int ts = 0; ts < 8; ++ts) {
+                        const int fn = 8 * c + ts + 2;             // (wraps to fragment 0 / 1 after the last block: harmless)
+                        const P3 wq2 = load_frag3(img_qkv, fn < 24 ? fn : fn - 24, lane);
+                        if (v_img) mma6(bp[ts >> 1], wq0, acc[ts & 1]);
+                        else mma6(wq0, bp[ts >> 1], acc[ts & 1]);
+                        wq0 = wq1; wq1 = wq2;
+                    }
                 }
                 if (v_img) {
                     // lane (li, h): head hd = 8 nt + (li >> 2), dim d = li & 3.  Accumulator registers 4 g2 + e and 4 (g2 + 2) + e
