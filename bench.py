@@ -72,7 +72,7 @@ def attention_roofline(dm, B, L, H, device, K, reps=3):
     tf = flops / (ms * 1e-3) / 1e12
     traffic = None
     if (B2, L, H) == (32, 4096, 16):
-        traffic = (2 * 82019.4 + 42038.2) * 1024      # profiles/r1_pmc_traffic.csv, d3pm_attention_v4_kernel
+        traffic = (2 * 82033.7 + 33294.3) * 1024      # profiles/r1_pmc_traffic.csv, d3pm_attention_v4_kernel<384>
     return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel", "achieved": round(tf, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "ms_per_launch": round(ms, 4), "launches_timed": len(events), "flops_per_launch": flops}
