@@ -185,9 +185,16 @@ def main():
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "hipgraph": not args.no_graph},
         }
-        line["roofline"] = attention_roofline(dm, B, L, 16, device, args.codes)
+        # the two side measurements must never cost the run its JSON line
+        try:
+            line["roofline"] = attention_roofline(dm, B, L, 16, device, args.codes)
+        except Exception as e:                                   # noqa: BLE001
+            line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, dm, vq, L)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, dm, vq, L)
+            except Exception as e:                               # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
