@@ -148,8 +148,6 @@ class Text2ImageTransformer(nn.Module):
                 g2=blk.ln2.weight.contiguous(), b2=blk.ln2.bias.contiguous(),
                 w1=blk.mlp[0].weight.contiguous(), bb1=blk.mlp[0].bias.contiguous(),
                 w2=blk.mlp[2].weight.contiguous(), bb2=blk.mlp[2].bias.contiguous())
-            if lay["w2"].shape == (64, 256) and lay["wqkv"].shape == (192, 64):       # the fused layer kernel's shape
-                lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
             p["layers"].append(lay)
         p["gf"], p["bf"] = self.to_logits[0].weight.contiguous(), self.to_logits[0].bias.contiguous()
         p["wl"], p["bl"] = self.to_logits[1].weight.contiguous(), self.to_logits[1].bias.contiguous()
@@ -183,6 +181,9 @@ class Text2ImageTransformer(nn.Module):
         ops.d3pm_embed(tok, p["emb"], p["pos"], x, rep=rep, stream=stream)
         layers = p["layers"]
         if Te == 1 and D == 64 and hbuf.shape[1] == 256:
+            if "w2_x3" not in layers[0]:          # bf16x3 weight fragment images of the fused layer kernel: made on first use
+                for lay in layers:                # (the training step re-packs every iteration and never needs them)
+                    lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
             # fused path: [AdaLN+qkv] for block 0, then per block attention + one fused kernel that also emits the
             # next block's q|k|v
             # The `rep` stacked copies (classifier-free guidance: conditional + unconditional) share tokens and timesteps, so

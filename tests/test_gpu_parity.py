@@ -378,7 +378,9 @@ def test_fused_layer_variants_agree(G):
     with torch.no_grad():
         for p_ in tr.parameters():
             p_.mul_(8.0)                      # N(0, 0.02) init would make every block nearly the identity
-    lay0, lay1 = tr.packed()["layers"]
+    lay0, lay1 = (dict(l) for l in tr.packed()["layers"])
+    for lay in (lay0, lay1):                  # the sampler makes these on first use
+        lay["w2_x3"], lay["wqkv_x3"] = G.ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
     M = B2 * L
     y = torch.randn(M, Dm, device="cuda")
     x_in = torch.randn(M, Dm, device="cuda")

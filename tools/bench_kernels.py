@@ -60,6 +60,8 @@ def main():
         tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
                                             content_spatial_size=[64, 64], diffusion_step=100).cuda()
         p = tr.packed()
+        for lay in p["layers"]:               # bf16x3 weight fragment images (the sampler makes them on first use)
+            lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
         x = torch.randn((M, D), device=dev); y = torch.randn((M, D), device=dev)
         qkv = torch.empty((3 * H, M, 4), device=dev)
         cv = torch.randn((B2, D), device=dev)
