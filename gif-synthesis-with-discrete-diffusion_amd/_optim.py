@@ -14,8 +14,10 @@ class GradArena:
 
     def __init__(self, device, capacity=0):
         self.device, self.buf, self.off, self.want = device, None, 0, int(capacity)
+        self.spilled = False               # a request of this step did not fit (its tensor lives outside the buffer)
 
     def reset(self):
+        self.spilled = False
         if self.buf is None or self.buf.numel() < self.want:
             self.buf = torch.zeros((self.want,), dtype=torch.float32, device=self.device)
         else:
@@ -31,6 +33,7 @@ class GradArena:
             v = self.buf[self.off:self.off + n].view(shape)
             self.off += n4
             return v
+        self.spilled = True
         return torch.zeros(shape, dtype=torch.float32, device=self.device)
 
     def zeros_like(self, t):
@@ -50,6 +53,18 @@ class MultiAdam:
         self.m = torch.zeros((int(self.offs[-1]),), dtype=torch.float32, device=dev)
         self.v = torch.zeros_like(self.m)
         self._key, self._table = None, None
+
+    def state(self):
+        return {"m": self.m.detach().cpu(), "v": self.v.detach().cpu(), "step": int(self.step_count)}
+
+    def load_state(self, st):
+        if st is None:
+            return
+        if st["m"].numel() != self.m.numel():
+            raise ValueError(f"Adam state holds {st['m'].numel()} values, this parameter list needs {self.m.numel()}")
+        self.m.copy_(st["m"])
+        self.v.copy_(st["v"])
+        self.step_count = int(st["step"])
 
     def _build_table(self, grads):
         rows = []

@@ -76,7 +76,14 @@ def load_reference_checkpoint(module, path_or_state, prefix="auto"):
 
 
 def lightning_state(generator=None, autoencoder=None):
-    """A Lightning-layout state_dict ("generator." / "autoencoder." prefixes) the reference's load_checkpoints can read."""
+    """A Lightning-layout state_dict with the attribute prefixes "generator." / "autoencoder.".
+
+    What the reference can read back: its load_checkpoints (multistage_text_motion_model.py:113-122) strips exactly 10
+    characters -- len("generator.") -- from EVERY key of whichever file it opens.  So a VQ-VAE meant for the reference's stage 2
+    must be exported the way its own stage 1 saves it, as `lightning_state(generator=vqvae)` (TextMotionModel holds the VQ-VAE as
+    `self.generator`); keys written under "autoencoder." (12 characters) would come out mangled there.  A stage-2 file
+    (`generator=<DiscreteDiffusion>, autoencoder=<VQVAE>`) is this build's own resume format and loads through
+    load_reference_checkpoint's prefix selection."""
     out = {}
     for prefix, mod in (("generator.", generator), ("autoencoder.", autoencoder)):
         if mod is not None:

@@ -34,6 +34,38 @@ __global__ void gelu2_bwd_kernel(const float* du, const float* a, float* da, int
                                                      g.w * gelu2_grad(v.w));
 }
 
+// ------------------------------------------------------------------ LayerNorm forward for the training step, C = 64, 16 lanes per row:
+//   stats[row] = (mean, rstd) (two-pass, biased variance, like nn.LayerNorm) and y = (x - mean) * rstd * gamma[sel] + beta[sel]
+//   in one pass over x (the training step keeps y: it is the weight-gradient operand of the GEMM that consumes it)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t M, float eps, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const int64_t* __restrict__ sel, int gstride,
+                                                     int rows_per_batch, float* __restrict__ stats, float* __restrict__ y) {
+    const int lane16 = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool ok = row < M;
+    const int64_t rc = ok ? row : 0;
+    const int c = lane16 * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + rc * 64 + c);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.f / 64.f);
+    const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+    float q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q * (1.f / 64.f) + eps);
+    const int b = (int)((uint32_t)rc / (uint32_t)rows_per_batch);
+    const int64_t sl = sel != nullptr ? sel[b] : 0;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + sl * gstride + c);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + sl * gstride + c);
+    if (ok) {
+        if (lane16 == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+        *reinterpret_cast<float4*>(y + row * 64 + c) =
+            make_float4(a0 * rstd * g.x + bt.x, a1 * rstd * g.y + bt.y, a2 * rstd * g.z + bt.z, a3 * rstd * g.w + bt.w);
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward, C = 64, 16 lanes per row
 //   h = xhat * gamma[sel] + beta[sel],  xhat = (x - mean) * rstd
 //   dx_out = dx_in + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dh * gamma
@@ -445,6 +477,17 @@ extern "C" int gsdd_gelu2(const float* a, const float* du, float* out, int64_t n
     const unsigned grid = (unsigned)((n / 4 + 255) / 256);
     if (backward) hipLaunchKernelGGL(gelu2_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, du, a, out, n);
     else hipLaunchKernelGGL(gelu2_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, out, n);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_ln_fwd(const float* x, int64_t M, int C, float eps, const float* gamma, const float* beta, const int64_t* sel,
+                           int gstride, int rows_per_batch, float* stats, float* y, void* stream) {
+    GSDD_CHECK_ARG(x && gamma && beta && stats && y, "null pointer");
+    GSDD_CHECK_ARG(C == 64 && M > 0 && rows_per_batch > 0, "C must be 64");
+    GSDD_CHECK_ARG(sel != nullptr || gstride == 0, "gstride needs a row selector");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, M, eps, gamma,
+                       beta, sel, gstride, rows_per_batch, stats, y);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

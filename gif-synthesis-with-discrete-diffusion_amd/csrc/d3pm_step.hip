@@ -6,6 +6,8 @@
 //
 // Mirrors the reference op-for-op in fp32 (diffusion_transformer.py:220-283, :354-359); the
 // reference's fp64 log_softmax (:231) is matched by accumulating the exp-sum and taking its log in fp64.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace gsdd {
@@ -129,8 +131,11 @@ __device__ __forceinline__ int wave_argmax(float v, int idx) {
 // Everything that depends only on the position (token, timestep, schedule row, which register slot holds class x_t)
 // is wave-uniform: the wave index goes through readfirstlane so that the compiler keeps it in SGPRs, and the
 // "k == x_t" special case becomes a scalar branch on j plus one lane compare instead of a compare+select per class.
-template <int J, bool FULL, bool DBG>
-__global__ __launch_bounds__(256, 3) void d3pm_step_kernel(gsdd_step_desc d, SchedPtrs sp) {
+// OCC = waves per SIMD the register budget is sized for: 3 -> 168 VGPRs, 2 -> 256.  At K = 4096 (J = 16) the two 64-register
+// rows plus the temporaries of the unrolled class loops need ~180: with OCC = 3 the compiler parks 8 of them in scratch memory
+// (2 KB written per position, 131 MB per launch at B*L = 65536 -- the WRITE_SIZE of profiles/r1_pmc_traffic.csv); OCC = 2 has none.
+template <int J, bool FULL, bool DBG, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void d3pm_step_kernel(gsdd_step_desc d, SchedPtrs sp) {
     const int lane = threadIdx.x & 63;
     const int64_t pos = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (pos >= (int64_t)d.B * d.L) return;
@@ -697,6 +702,12 @@ extern "C" int gsdd_d3pm_step(const gsdd_step_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int J = (d->K + 255) / 256;
     const bool dbg = d->post_dbg != nullptr || d->x0_dbg != nullptr;
+    static const int occ_env = [] { const char* e = getenv("GSDD_STEP_OCC"); return e ? atoi(e) : 0; }();
+    if (J > 8 && J <= 16 && d->K == 4096 && !dbg && occ_env != 3) {       // the production shape: no scratch (see the kernel's note)
+        hipLaunchKernelGGL((d3pm_step_kernel<16, true, false, 2>), grid, block, 0, st, *d, sp);
+        GSDD_CHECK_LAUNCH();
+        return GSDD_OK;
+    }
 #define GSDD_STEP_LAUNCH(JJ)                                                                                         \
     do {                                                                                                             \
         const bool full = d->K == 256 * (JJ);                                                                        \

@@ -101,6 +101,20 @@ __global__ __launch_bounds__(1024) void codebook_ema_n_kernel(float* N, const fl
     if (threadIdx.x == 0) { n_sum[0] = (float)tot; perplexity[0] = expf(-(float)red[0]); }
 }
 
+// perplexity of the LOCAL one-hot mean (videogpt_vq_vae.py:218-219: avg_probs = mean(encode_onehot) over this rank's latents)
+__global__ __launch_bounds__(1024) void code_perplexity_kernel(const float* n_local, int K, int64_t M, float* out) {
+    __shared__ double red[1024];
+    double h = 0.0;
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        const float p = n_local[k] / (float)M;
+        h += (double)(p * logf(p + 1e-10f));
+    }
+    red[threadIdx.x] = h;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = expf(-(float)red[0]);
+}
+
 // z_avg <- 0.99 z_avg + 0.01 encode_sum ; emb = z_avg / weights, dead codes (N < 1) restart from k_rand
 __global__ void codebook_ema_emb_kernel(const float* N, float* z_avg, float* emb, const float* encode_sum, const float* z,
                                         const int64_t* perm, int K, int E, float decay, const float* n_sum) {
@@ -180,6 +194,13 @@ extern "C" int gsdd_codebook_ema(const float* z, const int64_t* idx, int64_t M, 
         hipLaunchKernelGGL(codebook_ema_emb_kernel, dim3((K * E + 255) / 256), dim3(256), 0, st, N, z_avg, embeddings,
                            encode_sum, z, perm, K, E, decay, scalars);
     }
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_code_perplexity(const float* n_local, int K, int64_t M, float* out, void* stream) {
+    GSDD_CHECK_ARG(n_local && out && K > 0 && M > 0, "bad args");
+    hipLaunchKernelGGL(code_perplexity_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_local, K, M, out);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -153,6 +153,15 @@ class Text2ImageTransformer(nn.Module):
         p["wl"], p["bl"] = self.to_logits[1].weight.contiguous(), self.to_logits[1].bias.contiguous()
         return p
 
+    def fragment_images(self, stream=None):
+        """bf16x3 weight fragment images of the fused layer kernel, made on the sampler's first use after the weights changed
+        (the training step re-packs every iteration and never needs them).  Enqueued on `stream`: every stream that reads them
+        must be ordered after it (sample() builds them on the caller's stream before its lanes fork)."""
+        layers = self.packed()["layers"]
+        if self.n_embd == 64 and layers and "w2_x3" not in layers[0] and layers[0]["w1"].shape[0] == 256:
+            for lay in layers:
+                lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
+
     # ------------------------------------------------------------------ one denoiser pass on the HIP path
     def cond_vectors(self, cond):
         """Per-layer cross-attention operands of the condition tokens (B2, Te, cond_dim).
@@ -181,9 +190,7 @@ class Text2ImageTransformer(nn.Module):
         ops.d3pm_embed(tok, p["emb"], p["pos"], x, rep=rep, stream=stream)
         layers = p["layers"]
         if Te == 1 and D == 64 and hbuf.shape[1] == 256:
-            if "w2_x3" not in layers[0]:          # bf16x3 weight fragment images of the fused layer kernel: made on first use
-                for lay in layers:                # (the training step re-packs every iteration and never needs them)
-                    lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
+            self.fragment_images(stream)
             # fused path: [AdaLN+qkv] for block 0, then per block attention + one fused kernel that also emits the
             # next block's q|k|v
             # The `rep` stacked copies (classifier-free guidance: conditional + unconditional) share tokens and timesteps, so
@@ -349,7 +356,7 @@ class DiffusionTransformer(nn.Module):
         self.noise_seed = 0          # Philox key; the stream id advances with every draw
         self.noise_stream = 0
         self.row_offset = 0          # global row of this rank's first sample (multi-GPU batch sharding)
-        self.sample_lanes = 1        # concurrent sub-batches of sample() (see there); bench.py sets 2
+        self.sample_lanes = 1        # concurrent sub-batches of sample() (see there); `bench.py --lanes N` overrides it
         self._graph_cache = {}
 
     @property
@@ -392,6 +399,8 @@ class DiffusionTransformer(nn.Module):
         Bs = B // lanes
         toks, graphs = [], []
         cur = torch.cuda.current_stream()
+        tr.packed()                                 # packed weights, AdaLN tables and the fragment images are (re)built HERE, on the
+        tr.fragment_images()                        # caller's stream: each lane's wait_stream(cur) below then orders its reads after them
         for ln in range(lanes):
             st = self._streams[ln]
             st.wait_stream(cur)
@@ -543,46 +552,80 @@ class DiffusionTransformer(nn.Module):
         return out
 
 
+def _instantiate(cfg):
+    """discrete_diffusion.py:11-12: plain dicts (hydra_lite's composition) or DictConfigs (real hydra, when installed)."""
+    if isinstance(cfg, dict):
+        from .hydra_lite import instantiate
+    else:
+        from hydra.utils import instantiate
+    return instantiate(cfg)
+
+
 class DiscreteDiffusion(nn.Module):
     """Drop-in for src/models/networks/discrete_diffusion.py:8-83 (generator glue).  `textencoder` and
-    `diffusion_model` may be already-built modules or (with hydra present) configs to instantiate."""
+    `diffusion_model` may be already-built modules or (with hydra present) configs to instantiate.
 
-    def __init__(self, textencoder, diffusion_model, **kwargs):
+    zero_text_emb=True is the reference as written: both text embeddings are replaced by zeros (discrete_diffusion.py:25, :49).
+    False lets the captions condition the denoiser."""
+
+    def __init__(self, textencoder, diffusion_model, zero_text_emb=True, **kwargs):
         super().__init__()
         if not isinstance(textencoder, nn.Module) and not callable(textencoder):
-            from hydra.utils import instantiate
-            textencoder = instantiate(textencoder)
+            textencoder = _instantiate(textencoder)
         if not isinstance(diffusion_model, nn.Module):
-            from hydra.utils import instantiate
-            diffusion_model = instantiate(diffusion_model)
+            diffusion_model = _instantiate(diffusion_model)
         self.textencoder = textencoder
         self.diffusion_model = diffusion_model
+        self.zero_text_emb = bool(zero_text_emb)
 
-    @torch.no_grad()
+    def _text(self, texts, dev):
+        emb = self.textencoder(texts)
+        emb = emb.unsqueeze(1).to(dev)
+        return torch.zeros_like(emb) if self.zero_text_emb else emb.float()
+
     def forward(self, batch, autoencoder, length_estimator=None, do_inference=False):
         """discrete_diffusion.py:16-83: encode -> diffusion objective -> [sample] -> decode; same output-dict keys.
-        (Forward values only; the reference also zeroes the text embeddings, :25 and :49.)"""
-        x = batch["video"].to(autoencoder.device)
-        quant = autoencoder.encode(x)
+        `losses` carries the HIP backward's grad_fn when autograd is enabled and the denoiser is in train mode, so the caller's
+        `manual_backward(loss)` (multistage_text_motion_model.py:186-197) fills the transformer's .grad.  Encode, both decodes
+        and the sampler are not differentiable in the reference either (arg-min / arg-max cut the graph) and run under no_grad."""
+        dev = autoencoder.device
+        x = batch["video"].to(dev)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data parallel: this rank's clips are rows rank*B.. of the global batch, so the ranks draw different noise
+            self.diffusion_model.row_offset = dist.get_rank() * x.shape[0]
+        with torch.no_grad():
+            quant = autoencoder.encode(x)
         quant_flat = quant.view(x.shape[0], -1)
-        text_emb = torch.zeros_like(self.textencoder(batch["text"]).unsqueeze(1).to(autoencoder.device))
+        with torch.no_grad():
+            text_emb = self._text(batch["text"], dev)
         diffusion_out = self.diffusion_model({"condition_embed_token": text_emb, "content_token": quant_flat},
                                              return_loss=True)
-        single_step_out = autoencoder.decode(diffusion_out["pred_data"].view(quant.shape).clamp(max=autoencoder.n_codes - 1))
-        test = autoencoder.decode(quant)
-        out = {"pred_data": single_step_out, "gt_data": x, "losses": diffusion_out["loss"], "test": test}
+        with torch.no_grad():
+            # arg-max over K+1 classes can only return [MASK] when every code row sits at the -70 clamp; the reference would
+            # then fail inside F.embedding, we decode code K-1 instead
+            single_step_out = autoencoder.decode(diffusion_out["pred_data"].view(quant.shape).clamp(max=autoencoder.n_codes - 1))
+            if do_inference:
+                inference_out = self.sample_videos(batch["text"], autoencoder, latent_shape=tuple(quant.shape[1:]),
+                                                   text_emb=text_emb)
+            test = autoencoder.decode(quant)
         if do_inference:
-            out["pred_single_step"] = single_step_out
-            out["pred_data"] = self.sample_videos(batch["text"], autoencoder, latent_shape=tuple(quant.shape[1:]))
-        return out
+            return {"pred_data": inference_out, "pred_single_step": single_step_out, "gt_data": x,
+                    "losses": diffusion_out["loss"], "test": test}
+        return {"pred_data": single_step_out, "gt_data": x, "losses": diffusion_out["loss"], "test": test}
 
     @torch.no_grad()
-    def sample_videos(self, texts, autoencoder, latent_shape=None):
+    def sample_videos(self, texts, autoencoder, latent_shape=None, text_emb=None):
         """The inference branch of forward (discrete_diffusion.py:44-62): text -> tokens -> decoded clips."""
         dev = autoencoder.device
         B = len(texts)
-        text_emb = torch.zeros_like(self.textencoder(texts).unsqueeze(1).to(dev))      # (sic) :25 zeroes it
-        cf_emb = torch.zeros_like(self.textencoder([""] * B).unsqueeze(1).to(dev))      # :49
+        if text_emb is None:
+            text_emb = self._text(texts, dev)
+        cf_emb = self._text([""] * B, dev)                                              # :46-49
         out = self.diffusion_model.sample(texts, None, text_emb, cf_emb, content_token=None, filter_ratio=0)
+        self.last_content_token = out["content_token"]
         shape = latent_shape if latent_shape is not None else autoencoder.latent_shape
         return autoencoder.decode(out["content_token"].view(B, *shape))
+
+    def get_text_embeddings(self, features):                                           # discrete_diffusion.py:91-94
+        return self.textencoder(features).unsqueeze(1)

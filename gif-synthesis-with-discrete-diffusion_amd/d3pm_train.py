@@ -11,6 +11,9 @@ import torch.distributed as dist
 from . import ops
 from ._optim import GradArena, MultiAdam
 from ._lib import GsddError
+from .parallel import GradReducer, broadcast_module, world_size
+
+BUCKET_LAYERS = 5          # blocks per gradient bucket: 19 blocks + head + embeddings -> 5 all-reduces of ~2.7 MB each
 
 
 class D3PMTrainer:
@@ -18,6 +21,14 @@ class D3PMTrainer:
         self.dm, self.lr, self.betas, self.eps = dm, lr, betas, eps
         self.step_count = 0
         self.state = {}
+        self.reducer = GradReducer()
+        self._synced = False
+
+    def _sync_start(self):
+        """Once, before the first data-parallel step: every rank takes rank 0's parameters and buffers (what DDP does at wrap time)."""
+        if not self._synced and world_size() > 1:
+            broadcast_module(self.dm)
+        self._synced = True
 
     # ------------------------------------------------------------------ forward with saved activations
     def _forward(self, xt, cond, t):
@@ -28,8 +39,6 @@ class D3PMTrainer:
         M = B * L
         dev = xt.device
         f = dict(dtype=torch.float32, device=dev)
-        eye = torch.eye(D, **f)
-        zero_b = torch.zeros((D,), **f)
         cond = cond.float().contiguous()
         if cond.shape[1] != 1:
             raise NotImplementedError("the training step is built for one condition token (the reference call site)")
@@ -40,9 +49,8 @@ class D3PMTrainer:
         aws = ops.d3pm_attention_workspace(B, L, H, dev) if L % 32 == 0 else None     # pre-split K/V images (matrix-pipe forward)
         for lay in p["layers"]:
             s = {"x_in": x}
-            s["stats1"] = ops.row_stats(x, torch.empty((M, 2), **f))
-            ln1 = (s["stats1"], lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t, 2 * D)
-            s["hn"] = ops.linear(x, eye, torch.empty((M, D), **f), bias=zero_b, ln=ln1, rows_per_batch=L)
+            s["stats1"], s["hn"] = ops.ln_fwd(x, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], sel=t, gstride=2 * D,
+                                              rows_per_batch=L)          # AdaLayerNorm: statistics + normalised rows in one pass
             s["qkv"] = ops.linear(s["hn"], lay["wqkv"], torch.empty((3 * H, M, 4), **f), bias=lay["bqkv"], out_mode=2)
             s["y"], s["lse"] = torch.empty((M, D), **f), torch.empty((H * M,), **f)
             ops.d3pm_attention_train(s["qkv"][0:H], s["qkv"][H:2 * H], s["qkv"][2 * H:], B, L, H, s["y"], s["lse"], ws=aws)
@@ -50,23 +58,24 @@ class D3PMTrainer:
             cvec = ops.small_linear(s["v2"], lay["wproj2"], lay["bproj2"])
             s["x1"] = ops.linear(s["y"], lay["wproj"], torch.empty((M, D), **f), bias=lay["bproj"], bvec=cvec, rows_per_batch=L,
                                  residual=x)
-            s["stats2"] = ops.row_stats(s["x1"], torch.empty((M, 2), **f))
-            s["h2"] = ops.linear(s["x1"], eye, torch.empty((M, D), **f), bias=zero_b, ln=(s["stats2"], lay["g2"], lay["b2"], None, 0))
+            s["stats2"], s["h2"] = ops.ln_fwd(s["x1"], lay["g2"], lay["b2"])
             s["a"] = ops.linear(s["h2"], lay["w1"], torch.empty((M, lay["w1"].shape[0]), **f), bias=lay["bb1"])
             s["u"] = ops.gelu2(s["a"])
             x = ops.linear(s["u"], lay["w2"], torch.empty((M, D), **f), bias=lay["bb2"], residual=s["x1"])
             sv["layers"].append(s)
         sv["x_out"] = x
-        sv["statsf"] = ops.row_stats(x, torch.empty((M, 2), **f))
-        sv["hf"] = ops.linear(x, eye, torch.empty((M, D), **f), bias=zero_b, ln=(sv["statsf"], p["gf"], p["bf"], None, 0))
+        sv["statsf"], sv["hf"] = ops.ln_fwd(x, p["gf"], p["bf"])
         sv["logits"] = ops.linear(sv["hf"], p["wl"], torch.empty((M, p["wl"].shape[0]), **f), bias=p["bl"])
         return sv
 
     # ------------------------------------------------------------------ loss + gradients
     @torch.no_grad()
-    def loss_and_grads(self, x0, cond, t=None, pt=None, want_probs=False):
+    def loss_and_grads(self, x0, cond, t=None, pt=None, want_probs=False, reduce=False):
         """-> (loss tensor [1], {state_dict name: gradient}) for the transformer's parameters.  The gradients are views of one
-        arena that the next call re-uses; `self.last_fwd` keeps the forward's dict (x0_recon, per_sample, probs if asked)."""
+        arena that the next call re-uses; `self.last_fwd` keeps the forward's dict (x0_recon, per_sample, probs if asked).
+        reduce=True: the gradients come back averaged over the data-parallel group; the all-reduce runs in buckets of
+        BUCKET_LAYERS blocks issued while the backward of the earlier blocks is still being enqueued."""
+        self._sync_start()
         dm, tr = self.dm, self.dm.transformer
         if not x0.is_cuda:
             raise GsddError("the HIP path needs tensors on a ROCm device (no CPU fallback)")
@@ -97,6 +106,14 @@ class D3PMTrainer:
         if getattr(self, "_arena", None) is None:
             self._arena = GradArena(dev)
         self._arena.reset()                       # every gradient below is a zero-filled view of one buffer: one fill per step
+        red = self.reducer if (reduce and self.reducer.active()) else None
+        mark = [0]
+
+        def bucket():                             # all-reduce what the arena handed out since the last bucket (in place, async)
+            a = self._arena
+            if red is not None and a.buf is not None and mark[0] < a.off <= a.buf.numel():
+                red.add(a.buf[mark[0]:a.off])
+                mark[0] = a.off
 
         def z(name, like):
             g[name] = self._arena.zeros_like(like)
@@ -111,6 +128,7 @@ class D3PMTrainer:
         dx = ops.ln_bwd(dhf, sv["x_out"], sv["statsf"], p["gf"], dgamma=z("to_logits.0.weight", p["gf"]),
                         dbeta=z("to_logits.0.bias", p["bf"]), gacc_stride=D)
         del dlogits
+        bucket()
         bws = ops.d3pm_attention_bwd_workspace(B, L, H, dx.device) if L % 32 == 0 else None     # operand images (matrix-pipe backward)
         for i in reversed(range(len(p["layers"]))):
             lay, s = p["layers"][i], sv["layers"][i]
@@ -143,9 +161,9 @@ class D3PMTrainer:
             wq = z(pre + "_wqkv", lay["wqkv"])
             bq = z(pre + "_bqkv", lay["bqkv"])
             ops.wgrad(dqkv, s["hn"], wq, bq)
-            for j, nm in enumerate(("query", "key", "value")):
-                g[pre + f"attn1.{nm}.weight"] = wq[j * D:(j + 1) * D].contiguous()
-                g[pre + f"attn1.{nm}.bias"] = bq[j * D:(j + 1) * D].contiguous()
+            for j, nm in enumerate(("query", "key", "value")):        # row blocks of the fused gradient: views, already contiguous
+                g[pre + f"attn1.{nm}.weight"] = wq[j * D:(j + 1) * D]
+                g[pre + f"attn1.{nm}.bias"] = bq[j * D:(j + 1) * D]
             del g[pre + "_wqkv"], g[pre + "_bqkv"]
             dhn = ops.linear(dqkv, tw(lay["wqkv"]), torch.empty((B * L, D), **f))
             dtab = torch.zeros((B, 2 * D), **f)
@@ -154,40 +172,63 @@ class D3PMTrainer:
             ops.adaln_bwd(dtab, t, blk.ln1.emb.weight.contiguous(), blk.ln1.linear.weight.contiguous(),
                           z(pre + "ln1.emb.weight", blk.ln1.emb.weight), z(pre + "ln1.linear.weight", blk.ln1.linear.weight),
                           z(pre + "ln1.linear.bias", blk.ln1.linear.bias))
+            if (len(p["layers"]) - i) % BUCKET_LAYERS == 0:
+                bucket()
         # ---- embeddings
         ce = tr.content_emb
         Hs, Ws = ce.spatial_size
         dpos = self._arena.zeros((Hs * Ws, D))
         ops.d3pm_embed_bwd(dx, xt, z("content_emb.emb.weight", ce.emb.weight), dpos)
-        g["content_emb.height_emb.weight"] = ops.batch_rowsum(dpos, Hs, Ws)
+        ops.batch_rowsum(dpos, Hs, Ws, out=z("content_emb.height_emb.weight", ce.height_emb.weight))
         dw_ = self._arena.zeros((Ws * D,))
         ops.colsum(dpos.view(Hs, Ws * D), dw_)
         g["content_emb.width_emb.weight"] = dw_.view(Ws, D)
+        if red is not None:
+            bucket()
+            a = self._arena
+            lo = a.buf.data_ptr() if a.buf is not None else 0
+            done = lambda t: lo and lo <= t.data_ptr() < lo + 4 * mark[0]         # inside a bucket that has been issued
+            rest = [n for n, _ in tr.named_parameters() if not done(g[n])]
+            if rest:                              # the first step (arena not sized yet): whatever lives outside goes in one bucket
+                flat = torch.cat([g[n].reshape(-1) for n in rest])
+                red.add(flat)
+                off = 0
+                for n in rest:
+                    k = g[n].numel()
+                    g[n] = flat[off:off + k].view(g[n].shape)
+                    off += k
+            red.finish()
         return fwd["loss"], g
 
     # ------------------------------------------------------------------ optimiser step (Adam) with DP averaging
     @torch.no_grad()
     def step(self, x0, cond, t=None, pt=None):
-        loss, grads = self.loss_and_grads(x0, cond, t, pt)
+        loss, grads = self.loss_and_grads(x0, cond, t, pt, reduce=True)
         tr = self.dm.transformer
         params = dict(tr.named_parameters())
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            flat = torch.cat([grads[n].reshape(-1) for n in params])          # one bucket: ~3.4 M floats (13 MB)
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for n in params:
-                k = grads[n].numel()
-                grads[n] = flat[off:off + k].view_as(grads[n])
-                off += k
         self.step_count += 1
         if getattr(self, "_adam", None) is None:
             self._adam = MultiAdam(list(params.items()), self.lr, self.betas, self.eps)
+            self._adam.load_state(getattr(self, "_pending_adam", None))
+            self._pending_adam = None
         self._adam.lr = self.lr
         self._adam.step(grads)                  # all parameters in one launch
         tr._packed = None                       # parameters changed in place through raw pointers
         return loss
+
+
+    # ------------------------------------------------------------------ optimiser state for checkpoints (exact resume)
+    def optimizer_state(self):
+        a = getattr(self, "_adam", None)
+        return a.state() if a is not None else getattr(self, "_pending_adam", None)
+
+    def load_optimizer_state(self, state):
+        if state is None:
+            return
+        if getattr(self, "_adam", None) is not None:
+            self._adam.load_state(state)
+        else:
+            self._pending_adam = state
 
 
 class _TrainForward(torch.autograd.Function):
@@ -198,7 +239,7 @@ class _TrainForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, trainer, x0, cond, want_probs, *params):
-        loss, grads = trainer.loss_and_grads(x0, cond, want_probs=want_probs)
+        loss, grads = trainer.loss_and_grads(x0, cond, want_probs=want_probs, reduce=True)    # DDP semantics: .grad = group mean
         names = [n for n, _ in trainer.dm.transformer.named_parameters()]
         ctx.grads = [grads[n].clone() for n in names]          # the arena is re-used by the next forward
         return loss[0].clone()

@@ -6,6 +6,7 @@ import copy
 import importlib
 import os
 import re
+import time
 
 import yaml
 
@@ -70,8 +71,15 @@ def _compose_file(config_dir, rel, group_dir, group_choice):
             _merge(out, own)
             self_done = True
             continue
-        if isinstance(item, str):
-            item = {item: None}
+        if isinstance(item, str) and (item.startswith("/") or "@" in item):
+            item = {item: None}                       # `/group/file@package`: the path is the file
+        if isinstance(item, str):                     # a bare file name: a sibling in this file's group, merged in place
+            try:                                      # (configs/callbacks/default.yaml: `- model_checkpoint.yaml`)
+                _merge(out, _compose_file(config_dir, os.path.join(group_dir, item), group_dir, {}))
+            except FileNotFoundError:
+                if not item.startswith("optional "):
+                    raise
+            continue
         (key, choice), = item.items()
         optional = key.startswith("optional ")
         key = key.replace("optional ", "").strip()
@@ -111,6 +119,8 @@ def _resolve(root, node, where=()):
     """``where`` is the key path of the container that holds ``node`` (for ``${.sibling}`` / ``${..uncle}``)."""
     if isinstance(node, dict):
         for k in list(node):
+            if not where and k == "hydra":            # hydra's own node (run/sweep dir patterns with ${hydra.job.*}): resolved only
+                continue                              # where something points into it, and dropped from the result like hydra does
             node[k] = _resolve(root, node[k], where + (k,))
         return node
     if isinstance(node, list):
@@ -125,11 +135,27 @@ def _resolve(root, node, where=()):
     return node
 
 
+_NOW = [None]                                          # one clock reading per compose(), like hydra's ${now:...}
+
+
 def _lookup(root, dotted, holder=()):
-    """Value of an interpolation key and the key path it was found at."""
+    """Value of an interpolation key and the key path it was found at.  Resolvers: oc.env, now, hydra:runtime.{cwd,output_dir}
+    (the ones the reference's configs/paths/default.yaml and configs/hydra/default.yaml use)."""
     if dotted.startswith("oc.env:"):
         name, _, default = dotted[7:].partition(",")
+        if name not in os.environ and not _:
+            raise KeyError(f"environment variable '{name}' is not set (configs/paths/default.yaml needs PROJECT_ROOT; "
+                           "src/train.py and src/eval.py set it)")
         return os.environ.get(name, default), ()
+    if dotted.startswith("now:"):
+        return time.strftime(dotted[4:], _NOW[0] or time.localtime()), ()
+    if dotted.startswith("hydra:"):
+        what = dotted[6:]
+        if what == "runtime.cwd":
+            return os.getcwd(), ()
+        if what == "runtime.output_dir":
+            return "${hydra.run.dir}", ("hydra", "run")
+        raise KeyError(f"${{{dotted}}}: only hydra:runtime.cwd and hydra:runtime.output_dir are provided")
     base = ()
     if dotted.startswith("."):
         ups = len(dotted) - len(dotted.lstrip("."))
@@ -155,7 +181,10 @@ def compose(config_dir, config_name, overrides=()):
     cfg = _compose_file(config_dir, config_name, "", group_choice)
     for k, v in sets:
         _set_path(cfg, k, v)
-    return _wrap(_resolve(cfg, cfg, ()))
+    _NOW[0] = time.localtime()
+    cfg = _resolve(cfg, cfg, ())
+    cfg.pop("hydra", None)
+    return _wrap(cfg)
 
 
 def get_class(path):

@@ -119,11 +119,15 @@ def codebook_ema_stats(z, idx, K, stream=None):
     return n_total, encode_sum
 
 
-def codebook_ema_update(z, idx, perm, N, z_avg, emb, n_total, encode_sum, decay=0.99, stream=None):
+def codebook_ema_update(z, idx, perm, N, z_avg, emb, n_total, encode_sum, decay=0.99, n_local=None, m_local=None, stream=None):
+    """z: the restart-candidate rows (tiled / broadcast).  scalars[1] = perplexity of the local one-hot mean: pass this rank's
+    own counts `n_local` over its `m_local` latents whenever n_total was all-reduced or z was tiled."""
     M, E = z.shape
     scalars = torch.empty((2,), dtype=torch.float32, device=z.device)
     check(lib().gsdd_codebook_ema(ptr(z), ptr(idx), M, E, emb.shape[0], decay, ptr(perm), ptr(N), ptr(z_avg), ptr(emb),
                                   ptr(n_total), ptr(encode_sum), ptr(scalars), 1, stream_ptr(stream)))
+    if n_local is not None:
+        check(lib().gsdd_code_perplexity(ptr(n_local), emb.shape[0], m_local, ptr(scalars[1:]), stream_ptr(stream)))
     return scalars
 
 
@@ -336,6 +340,15 @@ def gelu2(a, du=None, stream=None):
     return out
 
 
+def ln_fwd(x, gamma, beta, *, sel=None, gstride=0, rows_per_batch=1, eps=1e-5, stream=None):
+    """-> (stats [M][2], y [M][64]): LayerNorm statistics and the normalised, scaled rows in one pass."""
+    stats = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(lib().gsdd_ln_fwd(ptr(x), x.shape[0], x.shape[1], eps, ptr(gamma), ptr(beta), ptr(sel), gstride, rows_per_batch,
+                            ptr(stats), ptr(y), stream_ptr(stream)))
+    return stats, y
+
+
 def ln_bwd(dh, x, stats, gamma, *, sel=None, gstride=0, rows_per_batch=1, dx_in=None, dgamma=None, dbeta=None,
            gacc_stride=0, acc_by_batch=False, stream=None):
     dx = torch.empty_like(x)
@@ -354,8 +367,9 @@ def colsum(Y, out, stream=None):
     check(lib().gsdd_colsum(ptr(Y), Y.shape[1], Y.shape[0], Y.shape[1], ptr(out), stream_ptr(stream)))
 
 
-def batch_rowsum(Y, B, L, stream=None):
-    out = torch.empty((B, Y.shape[1]), dtype=torch.float32, device=Y.device)
+def batch_rowsum(Y, B, L, out=None, stream=None):
+    if out is None:
+        out = torch.empty((B, Y.shape[1]), dtype=torch.float32, device=Y.device)
     check(lib().gsdd_batch_rowsum(ptr(Y), B, L, Y.shape[1], ptr(out), stream_ptr(stream)))
     return out
 

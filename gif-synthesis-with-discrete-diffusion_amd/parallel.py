@@ -1,6 +1,10 @@
-"""Multi-GPU layout of the sampling path: one process per GPU, the batch of independent clips is split across
-ranks, no data-path collective ("replicas").  Noise is keyed by the GLOBAL sample row
-(Philox counter = global_row * row_quads + quad), so the tokens a clip gets do not depend on the GPU count."""
+"""Multi-GPU layout: one process per GPU (torch.distributed.run), RCCL over xGMI (`backend="nccl"` is RCCL on ROCm).
+
+Sampling: the batch of independent clips is split across ranks, no data-path collective ("replicas").
+Noise is keyed by the GLOBAL sample row (Philox counter = global_row * row_quads + quad), so the tokens a clip gets do not depend
+on the GPU count.  Training: data parallel; parameters and buffers are broadcast from rank 0 once (what DDP does when it wraps a
+module), gradients are averaged by all-reduce in few large buckets issued while the backward is still running (xGMI is
+point-to-point: a ring all-reduce is bound by one link, so large messages, few launches)."""
 import os
 
 import torch
@@ -8,11 +12,29 @@ import torch.distributed as dist
 
 
 def init_distributed(backend=None):
-    """Join the job launched by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* from the env)."""
+    """Join the job launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).  Binds this
+    process to cuda:LOCAL_RANK BEFORE the process group exists (with nccl every rank would otherwise land on cuda:0).  A backend
+    that cannot initialise raises with the rendezvous it tried, rather than hanging later in the first collective."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+        backend = backend or os.environ.get("GSDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+        if torch.cuda.is_available():
+            n = torch.cuda.device_count()
+            if backend == "nccl" and local >= n:
+                raise RuntimeError(f"LOCAL_RANK {local} but only {n} GPU(s) visible: one process per GPU is the layout")
+            torch.cuda.set_device(local % max(n, 1))
+        try:
+            dist.init_process_group(backend)
+        except Exception as e:
+            raise RuntimeError(f"torch.distributed backend '{backend}' failed to initialise (WORLD_SIZE={world}, RANK="
+                               f"{os.environ.get('RANK')}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}, MASTER_PORT="
+                               f"{os.environ.get('MASTER_PORT')}): {e}") from e
     return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def shard_batch(global_batch, world, rank):
@@ -25,8 +47,91 @@ def shard_batch(global_batch, world, rank):
 
 def gather_tokens(tok):
     """Optional final gather of (B_local, L) int64 tokens to every rank (equal shard sizes assumed padded by caller)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if world_size() == 1:
         return tok
     parts = [torch.empty_like(tok) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, tok.contiguous())
     return torch.cat(parts, 0)
+
+
+@torch.no_grad()
+def broadcast_module(module, src=0):
+    """Every parameter and buffer takes rank `src`'s value (DDP's start-up broadcast): ranks that were not seeded identically
+    would otherwise average gradients taken at different weights and drift apart silently.  Also clears packed-weight caches."""
+    if world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_floating_point() or t.dtype in (torch.int64, torch.int32, torch.bool, torch.uint8):
+            dist.broadcast(t.data, src)
+    for m in module.modules():
+        if hasattr(m, "_packed"):
+            m._packed = None
+
+
+def assert_same_parameters(module, what="parameters"):
+    """Cheap drift check: the fp64 sum of all parameters must agree across ranks."""
+    if world_size() == 1:
+        return
+    s = torch.zeros(1, dtype=torch.float64, device=next(module.parameters()).device)
+    for p in module.parameters():
+        s += p.detach().double().sum()
+    lo, hi = s.clone(), s.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if lo.item() != hi.item():
+        raise RuntimeError(f"{what} differ across ranks (checksum {lo.item()} .. {hi.item()}): broadcast them first")
+
+
+class GradReducer:
+    """Mean of gradients over the data-parallel group, in buckets that are issued asynchronously while later backward kernels are
+    still being enqueued.  `add(t)` queues an in-place all-reduce of the flat fp32 tensor `t` (a slice of the trainer's gradient
+    arena, or a concatenation made by the caller); `finish()` waits for all of them and divides by the world size.  Records the
+    time from the first issue to the last completion (`last_ms`, HIP events on the current stream) so that the share of a step
+    spent in the exchange is a measured number."""
+
+    def __init__(self):
+        self.handles, self.tensors = [], []
+        self.last_ms, self.last_exposed_ms, self.last_bytes, self.last_buckets = 0.0, 0.0, 0, 0
+        self._ev = None
+
+    def active(self):
+        return world_size() > 1
+
+    def add(self, t):
+        if not self.active() or t.numel() == 0:
+            return
+        if not self.handles and t.is_cuda:
+            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+        self.tensors.append(t)
+        self.handles.append(dist.all_reduce(t, async_op=True))
+
+    def finish(self):
+        if not self.handles:
+            return
+        mid = None
+        if self._ev is not None:
+            mid = torch.cuda.Event(enable_timing=True)     # everything the backward enqueued is before this point
+            mid.record()
+        for h in self.handles:
+            h.wait()                                       # the current stream waits for the collective; the host does not block
+        w = float(dist.get_world_size())
+        for t in self.tensors:
+            t.div_(w)
+        self.last_bytes = sum(t.numel() * t.element_size() for t in self.tensors)
+        self.last_buckets = len(self.tensors)
+        if self._ev is not None:
+            self._ev[1].record()
+            self._pending = (self._ev[0], mid, self._ev[1])
+        self.handles, self.tensors, self._ev = [], [], None
+
+    def elapsed_ms(self):
+        """(span, exposed) of the last finished exchange in ms: first issue -> averaged gradients ready, and the part of it after the
+        backward's last kernel (what the step actually waits for).  Synchronises on the closing event."""
+        ev = getattr(self, "_pending", None)
+        if ev is None:
+            return 0.0, 0.0
+        ev[2].synchronize()
+        self.last_ms = ev[0].elapsed_time(ev[2])
+        self.last_exposed_ms = ev[1].elapsed_time(ev[2])
+        return self.last_ms, self.last_exposed_ms

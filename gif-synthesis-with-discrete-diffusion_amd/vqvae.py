@@ -371,10 +371,15 @@ class VQVAE(nn.Module):
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
     def encode(self, x, include_embeddings=False):
-        z, dims = self._encode_rows(x)
-        idx = torch.empty((z.shape[0],), dtype=torch.int64, device=z.device)
-        zq = torch.empty_like(z) if include_embeddings else None
-        ops.nearest_code(z, self.packed()["codebook"], idx, zq)
+        """videogpt_vq_vae.py:45-51.  In train mode the reference's encode runs BatchNorm on batch statistics and the codebook's
+        data-init / EMA update / restart (Codebook.forward :174-222 is mode-dependent) -- so does this one."""
+        if self.training:
+            z, dims, idx, zq, _, _ = self._quantise_train(x)
+        else:
+            z, dims = self._encode_rows(x)
+            idx = torch.empty((z.shape[0],), dtype=torch.int64, device=z.device)
+            zq = torch.empty_like(z) if include_embeddings else None
+            ops.nearest_code(z, self.packed()["codebook"], idx, zq)
         enc = idx.view(dims)
         if include_embeddings:
             emb_st = (zq - z) + z                                   # straight-through value (:216)
@@ -383,10 +388,14 @@ class VQVAE(nn.Module):
 
     @torch.no_grad()
     def decode(self, encodings):
+        """videogpt_vq_vae.py:53-56 (BatchNorm follows the module's mode, as there)."""
         if not encodings.is_cuda:
             raise GsddError("VQVAE runs on the HIP path only: move the module and the input to a ROCm device")
         enc = encodings.contiguous().long()
-        return self._decode_rows(self.packed()["codebook"], tuple(enc.shape), gather=enc.view(-1))
+        out = self._decode_rows(self.packed()["codebook"], tuple(enc.shape), gather=enc.view(-1), train=self.training)
+        if self.training:
+            self._packed = None                                     # BN running stats changed in place
+        return out
 
     def _tile(self, x):
         """Codebook._tile (videogpt_vq_vae.py:151-158): repeat + jitter when there are fewer latents than codes."""
@@ -414,10 +423,10 @@ class VQVAE(nn.Module):
         return y.contiguous(), perm
 
     @torch.no_grad()
-    def _forward_train(self, x):
-        """Train-mode forward value (videogpt_vq_vae.py:58-72 with Codebook.forward :174-222): BatchNorm batch statistics
-        + running-stat update, codebook data-init on the first call, EMA update with all-reduced statistics (C2) and
-        dead-code restart.  The backward lives in vqvae_trainer.py."""
+    def _quantise_train(self, x):
+        """Encoder + Codebook.forward in train mode (videogpt_vq_vae.py:174-222): BatchNorm batch statistics + running-stat
+        update, codebook data-init on the first call, EMA update with all-reduced statistics (C2) and dead-code restart.
+        -> (z rows, dims, idx, zq rows [the pre-update code vectors], commitment loss, (., perplexity))."""
         import torch.distributed as dist
         cb = self.codebook
         z, dims = self._encode_rows(x, train=True)
@@ -432,16 +441,26 @@ class VQVAE(nn.Module):
         zq = torch.empty_like(z)
         ops.nearest_code(z, cb.embeddings.contiguous(), idx, zq)
         commitment = ops.mse(z, zq, 0.25)
-        n_total, encode_sum = ops.codebook_ema_stats(z, idx, self.n_codes)
+        n_local, encode_sum = ops.codebook_ema_stats(z, idx, self.n_codes)
+        n_total = n_local
         if dist.is_available() and dist.is_initialized():               # C2 (:196-198)
+            n_total = n_local.clone()
             dist.all_reduce(n_total)
             dist.all_reduce(encode_sum)
         rows, perm = self._draw_rows(z)
-        scal = ops.codebook_ema_update(rows, idx, perm, cb.N, cb.z_avg, cb.embeddings, n_total, encode_sum)
+        scal = ops.codebook_ema_update(rows, idx, perm, cb.N, cb.z_avg, cb.embeddings, n_total, encode_sum,
+                                       n_local=n_local, m_local=z.shape[0])
+        self._packed = None                                             # BN running stats / codebook changed in place
+        return z, dims, idx, zq, commitment, scal
+
+    @torch.no_grad()
+    def _forward_train(self, x):
+        """Train-mode forward value (videogpt_vq_vae.py:58-72).  The backward lives in vqvae_trainer.py."""
+        z, dims, idx, zq, commitment, scal = self._quantise_train(x)
         emb_st = ((zq - z) + z).contiguous()
         x_recon = self._decode_rows(emb_st, dims, train=True)
         recon = ops.mse(x_recon, x, 1.0 / 0.06)
-        self._packed = None                                             # BN running stats / codebook changed in place
+        self._packed = None
         return {"pred_data": x_recon, "gt_data": x,
                 "losses": {"recon_loss": recon, "commitment_loss": commitment}, "perplexity": scal[1], "encodings": idx.view(dims)}
 

@@ -11,6 +11,7 @@ import torch.distributed as dist
 from . import ops
 from ._optim import MultiAdam
 from ._lib import GsddError
+from .parallel import GradReducer, broadcast_module, world_size
 from .vqvae import conv_taps, convT_phases, pack_conv0_weight
 
 
@@ -35,6 +36,14 @@ class VQVAETrainer:
         self.vq, self.lr, self.betas, self.eps = vq, lr, betas, eps
         self.step_count = 0
         self.state = {}
+        self.reducer = GradReducer()
+        self._synced = False
+
+    def _sync_start(self):
+        """Once, before the first data-parallel step: every rank takes rank 0's parameters and buffers (DDP's start-up broadcast)."""
+        if not self._synced and world_size() > 1:
+            broadcast_module(self.vq)
+        self._synced = True
 
     # ================================================================== forward with saved activations
     def _res_stack_fwd(self, h, dims, rp, stack):
@@ -103,11 +112,15 @@ class VQVAETrainer:
         zq = torch.empty_like(z)
         ops.nearest_code(z, cb.embeddings.contiguous(), idx, zq)
         commitment = ops.mse(z, zq, 0.25)
-        n_total, encode_sum = ops.codebook_ema_stats(z, idx, vq.n_codes)
+        n_local, encode_sum = ops.codebook_ema_stats(z, idx, vq.n_codes)
+        n_total = n_local
         if dist.is_available() and dist.is_initialized():
+            n_total = n_local.clone()
             dist.all_reduce(n_total); dist.all_reduce(encode_sum)
         rows, perm = vq._draw_rows(z)
-        ops.codebook_ema_update(rows, idx, perm, cb.N, cb.z_avg, cb.embeddings, n_total, encode_sum)
+        scal = ops.codebook_ema_update(rows, idx, perm, cb.N, cb.z_avg, cb.embeddings, n_total, encode_sum,
+                                       n_local=n_local, m_local=z.shape[0])
+        self.last_perplexity = scal[1]                      # of this rank's latents (videogpt_vq_vae.py:218-219)
         emb_st = ((zq - z) + z).contiguous()
         sv["z"], sv["zq"], sv["emb_st"] = z, zq, emb_st
         hp = ops.gemm(emb_st, p["post_w"], torch.empty((z.shape[0], vq.n_hiddens), **f), in_dims=dims, out_grid=dims[1:],
@@ -194,6 +207,7 @@ class VQVAETrainer:
             raise GsddError("the HIP path needs tensors on a ROCm device (no CPU fallback)")
         if not vq.training:
             raise GsddError("VQVAETrainer needs the module in train() mode (BatchNorm batch statistics, codebook EMA)")
+        self._sync_start()
         x = x.contiguous().float()
         p = vq.packed()                     # weights of THIS step (the forward invalidates the cache at its end)
         sv, losses = self._forward(x)
@@ -205,12 +219,29 @@ class VQVAETrainer:
         return losses, self.backward(sv, w_recon, w_commit)
 
     @torch.no_grad()
-    def backward(self, sv, w_recon=1.0, w_commit=1.0):
-        """Gradients of w_recon*recon_loss + w_commit*commitment_loss w.r.t. every parameter, keyed by state_dict name."""
+    def backward(self, sv, w_recon=1.0, w_commit=1.0, reduce=False):
+        """Gradients of w_recon*recon_loss + w_commit*commitment_loss w.r.t. every parameter, keyed by state_dict name.
+        reduce=True: averaged over the data-parallel group, in two buckets -- the decoder half (56 MiB at the full config) is
+        all-reduced while the encoder half's backward is still being enqueued, the encoder half at the end."""
         vq, p, x = self.vq, sv["p"], sv["x"]
         dev = x.device
         f = dict(dtype=torch.float32, device=dev)
         g = {}
+        red = self.reducer if (reduce and self.reducer.active()) else None
+        flushed = set()
+
+        def flush():
+            names = [n for n in g if n not in flushed]
+            if red is None or not names:
+                return
+            flat = torch.cat([g[n].reshape(-1) for n in names])
+            red.add(flat)
+            off = 0
+            for n in names:
+                k = g[n].numel()
+                g[n] = flat[off:off + k].view(g[n].shape)
+                off += k
+            flushed.update(names)
         C_, E = vq.n_hiddens, vq.embedding_dim
         dims = sv["dims"]
         B = x.shape[0]
@@ -293,6 +324,7 @@ class VQVAETrainer:
         demb = ops.gemm(dhp, p["post_w"][0].t().contiguous().view(1, E, C_), torch.empty((dhp.shape[0], E), **f), in_dims=dims,
                         out_grid=dims[1:])
         dz = ops.lincomb(demb, sv["z"], sv["zq"], w_commit * 0.25 * 2.0 / sv["z"].numel())
+        flush()                                                               # decoder half on its way
         # ---- pre_vq_conv (1x1, C -> E) with the encoder stack's trailing BN+ReLU as prologue
         dwpre = torch.zeros((1, E, C_), **f)
         ops.conv_wgrad(sv["enc_r"], dz, dwpre, in_dims=dims, out_grid=dims[1:], cin=C_, cout=E, pro=sv["enc_pro"])
@@ -337,29 +369,16 @@ class VQVAETrainer:
                     wT = torch.stack([wfull[a, b_, cc].t() for (a, b_, cc) in ks]).contiguous()     # [taps][Cin][Cout]
                     ops.gemm(dY, wT, dh, in_dims=(Bc,) + tuple(s["out_grid"]), out_grid=(Ti // stride[0], Hi // stride[1], Wi // stride[2]),
                              taps=ops.taps_tensor(offs, dev), ntaps=len(ks), out_dims=(Ti, Hi, Wi), out_step=stride, out_off=phase)
+        flush()
+        if red is not None:
+            red.finish()
         return g
 
     # ================================================================== optimiser step
     @torch.no_grad()
-    def all_reduce_grads(self, grads):
-        """Data-parallel mean of the gradients: one flat buffer (29 M floats = 110 MiB at the full config), one all-reduce."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return grads
-        names = [n for n, _ in self.vq.named_parameters()]
-        flat = torch.cat([grads[n].reshape(-1) for n in names])
-        dist.all_reduce(flat)
-        flat /= dist.get_world_size()
-        out, off = {}, 0
-        for n in names:
-            kk = grads[n].numel()
-            out[n] = flat[off:off + kk].view(grads[n].shape)
-            off += kk
-        return out
-
-    @torch.no_grad()
     def step(self, x):
-        losses, grads = self.loss_and_grads(x)
-        grads = self.all_reduce_grads(grads)
+        sv, losses = self.forward(x)
+        grads = self.backward(sv, 1.0, 1.0, reduce=True)
         self.step_count += 1
         if getattr(self, "_adam", None) is None:
             self._adam = MultiAdam(list(self.vq.named_parameters()), self.lr, self.betas, self.eps)
@@ -386,7 +405,7 @@ class _TrainForward(torch.autograd.Function):
     def backward(ctx, g_recon, g_commit, _g_pred):
         wr = 0.0 if g_recon is None else float(g_recon)
         wc = 0.0 if g_commit is None else float(g_commit)
-        grads = ctx.trainer.backward(ctx.sv, wr, wc)
+        grads = ctx.trainer.backward(ctx.sv, wr, wc, reduce=True)          # DDP semantics: .grad = mean over the group
         ctx.sv = None
         return (None, None) + tuple(grads[n] for n, _ in ctx.trainer.vq.named_parameters())
 

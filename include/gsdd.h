@@ -108,10 +108,15 @@ int gsdd_bn_train(const float* x, int64_t M, int C, const float* weight, const f
 /* Codebook EMA (Codebook.forward, videogpt_vq_vae.py:193-214) in two phases so the caller can all-reduce between them
  * (:196-198): phase 0: n_total[K], encode_sum[K][E] from (z rows, idx); phase 1: N, z_avg EMA with `decay`, Laplace-
  * smoothed embeddings, dead codes (N < 1) restarted from z[perm[k]] (:205-214).  scalars[0] = sum(N), scalars[1] =
- * perplexity (:218-219). */
+ * exp(-H(n_total / M)) (the perplexity when n_total is this rank's own count over M latents; otherwise use
+ * gsdd_code_perplexity on the local counts). */
 int gsdd_codebook_ema(const float* z, const int64_t* idx, int64_t M, int E, int K, float decay, const int64_t* perm,
                       float* N, float* z_avg, float* embeddings, float* n_total, float* encode_sum, float* scalars,
                       int phase, void* stream);
+
+/* out[0] = exp(-sum_k p_k log(p_k + 1e-10)), p_k = n_local[k] / M: the codebook perplexity of THIS rank's M latents
+ * (videogpt_vq_vae.py:218-219 take the mean of the local one-hot, before any all-reduce and before _tile). */
+int gsdd_code_perplexity(const float* n_local, int K, int64_t M, float* out, void* stream);
 
 /* out[0] = scale * mean((a-b)^2), deterministic fp64 two-stage reduction (F.mse_loss at videogpt_vq_vae.py:64, :190);
  * workspace >= 8 KiB. */
@@ -266,6 +271,12 @@ int gsdd_d3pm_train_loss_bwd(const gsdd_train_desc* d, float* dlogits, void* str
  * (autograd of transformer_utils.py:24-62, 138-159, 258-282, 353-356 and dalle_mask_image_embedding.py:59-79) */
 /* out = gelu2(a) (backward=0) or out = du * gelu2'(a) (backward=1), n % 4 == 0 */
 int gsdd_gelu2(const float* a, const float* du, float* out, int64_t n, int backward, void* stream);
+/* LayerNorm forward of the training step over rows of 64 (nn.LayerNorm / AdaLayerNorm, transformer_utils.py:138-159): stats[row] =
+ * (mean, rstd) and y = (x - mean) * rstd * gamma + beta in one pass; gamma/beta = base + sel[row / rows_per_batch] * gstride
+ * (sel NULL: one shared pair).  The sampler never materialises y (it is a GEMM prologue there); the training step keeps it as the
+ * weight-gradient operand. */
+int gsdd_ln_fwd(const float* x, int64_t M, int C, float eps, const float* gamma, const float* beta, const int64_t* sel, int gstride,
+                int rows_per_batch, float* stats, float* y, void* stream);
 /* LayerNorm backward over rows of 64: dx_out = dx_in + LN'(dh); dgamma/dbeta accumulated (+=) per batch element
  * (acc_by_batch, AdaLN table rows) or globally (affine LN).  gamma = gamma_base + sel[b]*gstride. */
 int gsdd_ln_bwd(const float* dh, const float* x, const float* stats, const float* gamma, const int64_t* sel, int gstride,

@@ -54,13 +54,17 @@ class ClipFolderDataModule:
         self.args = dict(data_folder=data_folder, sequence_length=sequence_length, resolution=resolution, **kwargs)
         self.batch_size, self.device, self.shuffle_seed = batch_size, device, shuffle_seed
         self.sequence_length, self.resolution = sequence_length, resolution
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)                          # the shuffle is a function of (shuffle_seed, epoch)
 
     def _loader(self, split, shuffle):
         from gsdd_amd.data import preprocess
         ds = ClipFolderDataset(split=split, **self.args)
         order = list(range(len(ds)))
         if shuffle:
-            order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(self.shuffle_seed)).tolist()
+            order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(self.shuffle_seed + self.epoch)).tolist()
         for i in range(0, len(order), self.batch_size):
             items = [ds[j] for j in order[i:i + self.batch_size]]
             video = torch.stack([preprocess(it["frames"].to(self.device), self.resolution) for it in items])   # (B,3,T,R,R)

@@ -9,10 +9,16 @@ class SyntheticClipDataModule:
                  **kwargs):
         self.sequence_length, self.resolution, self.batch_size = sequence_length, resolution, batch_size
         self.n_batches, self.seed, self.device = n_batches, seed, device
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        """Fresh training clips every epoch (a function of (seed, epoch, batch index) only: resuming at epoch e replays exactly
+        what an uninterrupted run would have seen)."""
+        self.epoch = int(epoch)
 
     def _loader(self, offset):
         for i in range(self.n_batches):
-            g = torch.Generator().manual_seed(self.seed + offset + i)
+            g = torch.Generator().manual_seed(self.seed + offset + i + (1_000_003 * self.epoch if offset == 0 else 0))
             B, T, R = self.batch_size, self.sequence_length, self.resolution
             yield {"video": torch.randn(B, 3, T, R, R, generator=g).to(self.device),
                    "text": [f"synthetic action {j % 101}" for j in range(B)], "length": [T] * B,

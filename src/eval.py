@@ -1,9 +1,10 @@
-"""`python src/eval.py model=discrete_diffusion ...` (reference: src/eval.py:8-13)."""
+"""`python src/eval.py model=discrete_diffusion ckpt_path=...` (reference: src/eval.py:8-13, src/tasks/eval_task.py:14-62)."""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("PROJECT_ROOT", ROOT)
 import src  # noqa: E402,F401
 from gsdd_amd.hydra_lite import compose  # noqa: E402
 

@@ -1,60 +1,147 @@
-"""Stage-2 wrapper (D3PM over VQ-VAE tokens): same constructor keys / hooks as the reference's
-MultistageTextMotionModel (src/models/multistage_text_motion_model.py:31-252).  The autoencoder runs in eval()
-(the reference leaves it in train mode by accident)."""
+"""Stage-2 wrapper (D3PM over VQ-VAE tokens): the reference's MultistageTextMotionModel
+(src/models/multistage_text_motion_model.py:21-281): same constructor keys, generator_step / sample_generator_step through the
+generator glue, manual optimisation (zero_grad -> manual_backward -> step, :186-200), ComputeLosses per model and split,
+epoch-end log keys, optimisers (opt_gen, opt_auto) = Adam(betas (0.5, 0.999)).
+
+Deliberate differences, each behind a flag that restores the reference's behaviour:
+  * `autoencoder_train_mode=False`: the VQ-VAE stays in eval() whatever `.train()` is called on the wrapper.  The reference never
+    freezes it (:104 is commented out), so there Lightning's `.train()` puts it in train mode and every `encode` moves the
+    BatchNorm running statistics and runs the codebook's EMA update on the stage-2 data.  True reproduces that.
+    (Its optimiser opt_auto is built in both cases, as in the reference, and never changes a weight: the D3PM loss reaches the
+    autoencoder only through arg-min indices, so its parameters have no gradient.)
+  * `step_in_eval_splits=False`: the reference calls `opt.step()` for every optimiser in the val/test splits too (:199-200),
+    re-applying the last training gradients; not reproduced unless asked for.
+  * `native_step=False`: True replaces zero_grad/backward/Adam by gsdd_amd.d3pm_train.D3PMTrainer.step (same arithmetic, one
+    arena + one Adam launch, data-parallel all-reduce built in)."""
 import torch
 
 from gsdd_amd.hydra_lite import instantiate
 from src.models.base import BaseModel
+from src.models.text_motion_model import _make_losses
 
 
 class MultistageTextMotionModel(BaseModel):
-    def __init__(self, generator, autoencoder, generator_losses=None, checkpoint_paths=None, evaluator=None,
-                 freeze_models_dict=None, lr_args={}, render_animations=True, do_evaluation=False, devices="cpu",
+    def __init__(self, generator, autoencoder, generator_losses=None, autoencoder_losses=None, length_estimator_losses=None,
+                 checkpoint_paths=None, evaluator=None, freeze_models_dict=None, lr_args={}, render_animations=True,
+                 do_evaluation=False, devices="cpu", autoencoder_train_mode=False, step_in_eval_splits=False, native_step=False,
                  **kwargs):
         super().__init__()
         self.gpu_device = devices if devices == "cpu" else "cuda:" + str(devices[0])
-        self.generator = instantiate(generator) if isinstance(generator, dict) else generator
+        self.generator = instantiate(generator, device=self.gpu_device, _recursive_=False) if isinstance(generator, dict) else generator
         self.autoencoder = instantiate(autoencoder, device=self.gpu_device, _recursive_=False) \
             if isinstance(autoencoder, dict) else autoencoder
-        ckpt = (checkpoint_paths or {}).get("autoencoder") if isinstance(checkpoint_paths, dict) else checkpoint_paths
-        if ckpt and ckpt != "__None__":                 # load_checkpoints (multistage_text_motion_model.py:113-122)
-            from gsdd_amd.checkpoint import load_reference_checkpoint
-            load_reference_checkpoint(self.autoencoder, ckpt)
-        gen_ckpt = (checkpoint_paths or {}).get("generator") if isinstance(checkpoint_paths, dict) else None
-        if gen_ckpt and gen_ckpt != "__None__":
-            from gsdd_amd.checkpoint import load_reference_checkpoint
-            load_reference_checkpoint(self.generator, gen_ckpt)
-        self.autoencoder.eval()
+        self.length_estimator = None
+        self.keys = ["generator", "autoencoder", "length_estimator"]
+        self.load_checkpoints(checkpoint_paths)
+        self.generator_losses = _make_losses(generator_losses) if generator_losses is not False else None
+        self.autoencoder_losses = _make_losses(autoencoder_losses) if autoencoder_losses else None
+        self.length_estimator_losses = _make_losses(length_estimator_losses) if length_estimator_losses else None
+        self.losses = (self.generator_losses, self.autoencoder_losses, self.length_estimator_losses)
         self.lr_args = dict(lr_args)
-        self.do_evaluation = do_evaluation
+        self.render_animations = render_animations
         self.automatic_optimization = False
+        self.loss_dict = {}
+        self.do_evaluation = do_evaluation
+        self.evaluator = instantiate(evaluator, device=self.gpu_device, _recursive_=False) if do_evaluation else None
+        self.autoencoder_train_mode = bool(autoencoder_train_mode)
+        self.step_in_eval_splits = bool(step_in_eval_splits)
+        self.native_step = bool(native_step)
+        self._native = None
+        if not self.autoencoder_train_mode:
+            self.autoencoder.eval()
 
-    def generator_step(self, batch):
-        return dict(self.generator(batch, self.autoencoder, None))
+    def train(self, mode=True):
+        super().train(mode)
+        if not self.autoencoder_train_mode:
+            self.autoencoder.eval()
+        return self
 
-    @torch.no_grad()
-    def sample_generator_step(self, batch):
-        clips = self.generator.sample_videos(batch["text"], self.autoencoder)
-        return {"pred_data": clips, "gt_data": batch.get("video")}
+    def load_checkpoints(self, checkpoint_paths):
+        """:69-70 / :113-122: a path, or {autoencoder|generator: path}; '__None__' / None = nothing to load."""
+        from gsdd_amd.checkpoint import load_reference_checkpoint
+        paths = checkpoint_paths if isinstance(checkpoint_paths, dict) else {"autoencoder": checkpoint_paths}
+        for key in ("generator", "autoencoder"):
+            path = paths.get(key)
+            if path and path != "__None__":
+                load_reference_checkpoint(getattr(self, key), path)
 
-    def allsplit_step(self, split, batch, batch_idx):
-        """train: one optimiser step of the D3PM generator on the HIP path (zero_grad -> backward -> Adam in the reference,
-        multistage_text_motion_model.py:186-197; here gsdd_amd.d3pm_train.D3PMTrainer.step, which also averages
-        gradients over the data-parallel group).  The autoencoder stays frozen in eval mode (auto_lr 1e-6 in the
-        reference is effectively a no-op and its backward is not built)."""
-        if split == "train":
-            from gsdd_amd.d3pm_train import D3PMTrainer
-            if getattr(self, "_trainer", None) is None:
-                self._trainer = D3PMTrainer(self.generator.diffusion_model, lr=self.lr_args.get("gen_lr", 1e-4))
-            with torch.no_grad():
-                x = batch["video"].to(self.autoencoder.device)
-                tokens = self.autoencoder.encode(x).view(x.shape[0], -1)
-                text_emb = torch.zeros_like(self.generator.textencoder(batch["text"]).unsqueeze(1).to(tokens.device))
-            loss = self._trainer.step(tokens, text_emb)[0]
-            self.log_dict({f"total/{split}": float(loss)})
-            return loss
-        return self.sample_generator_step(batch)
+    def generator_step(self, batch):                                    # :149-157
+        outputs = dict(self.generator(batch, self.autoencoder, self.length_estimator))
+        outputs["length"] = batch["length"]
+        return outputs
 
-    def configure_optimizers(self):
-        return [torch.optim.Adam(self.generator.parameters(), lr=self.lr_args.get("gen_lr", 1e-4), betas=(0.5, 0.999)),
-                torch.optim.Adam(self.autoencoder.parameters(), lr=self.lr_args.get("auto_lr", 1e-6))]
+    def sample_generator_step(self, batch):                             # :160-168
+        outputs = dict(self.generator(batch, self.autoencoder, self.length_estimator, do_inference=True))
+        outputs["length"] = batch["length"]
+        return outputs
+
+    def _native_train_step(self, batch):
+        from gsdd_amd.d3pm_train import D3PMTrainer
+        if self._native is None:
+            self._native = D3PMTrainer(self.generator.diffusion_model, lr=self.lr_args.get("gen_lr", 1e-4))
+            self._native.load_optimizer_state(getattr(self, "_native_state", None))
+        with torch.no_grad():
+            x = batch["video"].to(self.autoencoder.device)
+            tokens = self.autoencoder.encode(x).view(x.shape[0], -1)
+            text_emb = self.generator._text(batch["text"], tokens.device)
+        loss = self._native.step(tokens, text_emb)[0]
+        self.generator_losses["train"].update({"losses": loss})
+        self.loss_dict["generator_loss"] = loss
+        return self.loss_dict
+
+    def allsplit_step(self, split, batch, batch_idx):                   # :170-206
+        if split == "train" and self.native_step:
+            return self._native_train_step(batch)
+        optimizers = self.optimizers()
+        optimizers = list(optimizers) if isinstance(optimizers, (list, tuple)) else [optimizers]
+        outputs = self.generator_step(batch)
+        if self.do_evaluation and split != "train" and len(batch["length"]) != 1 and self.current_epoch % 5 == 0:
+            eval_outputs = self.sample_generator_step(batch)
+            self.evaluator.push_vals(batch, batch_idx, eval_outputs["pred_data"])
+        # (the reference zips the optimisers into this loop, :189; outside fit() Lightning hands back no optimisers, the zip is
+        # empty and its test split accumulates nothing -- here the losses are accumulated in every split)
+        for i, (loss, key) in enumerate(zip(self.losses, [k + "_loss" for k in self.keys])):
+            if loss:
+                self.loss_dict[key] = loss[split].update(outputs)
+                if split == "train":
+                    optimizers[i].zero_grad()
+                    self.manual_backward(self.loss_dict[key], retain_graph=False)
+        if split == "train" or self.step_in_eval_splits:
+            for opt in optimizers:
+                opt.step()
+        return self.loss_dict
+
+    def allsplit_epoch_end(self, split, outputs):                       # :208-238
+        s = "total/" + split
+        total_dico = {s: 0.0}
+        for loss in self.losses:
+            if loss:
+                dico = self._epoch_dico(loss[split], split)
+                dico.update({"epoch": float(self.trainer.current_epoch), "step": float(self.trainer.current_epoch)})
+                total = total_dico[s] + dico[s]
+                total_dico.update(dico)
+                total_dico[s] = total
+        if self.do_evaluation and split != "train" and self.current_epoch % 5 == 0:
+            metrics = self.evaluator.evaluate_metrics(self.trainer.datamodule, self.generator)
+            total_dico.update({f"Metrics/{m}-{split}": v for m, v in metrics.items()})
+            self.evaluator.reset()
+        if split == "val" and self.current_epoch % 10 == 0:
+            self.render_sample_results()
+        self.log_dict(total_dico)
+
+    def on_save_checkpoint(self, checkpoint):
+        super().on_save_checkpoint(checkpoint)
+        if self._native is not None:
+            checkpoint["gsdd"]["native_adam"] = self._native.optimizer_state()
+
+    def on_load_checkpoint(self, checkpoint):
+        super().on_load_checkpoint(checkpoint)
+        self._native_state = (checkpoint.get("gsdd") or {}).get("native_adam")
+        if self._native is not None:
+            self._native.load_optimizer_state(self._native_state)
+
+    def configure_optimizers(self):                                     # :240-252
+        b1, b2 = 0.5, 0.999
+        opt_gen = torch.optim.Adam(self.generator.parameters(), lr=self.lr_args.get("gen_lr", 1e-4), betas=(b1, b2))
+        opt_auto = torch.optim.Adam(self.autoencoder.parameters(), lr=self.lr_args.get("auto_lr", 1e-6), betas=(b1, b2))
+        return opt_gen, opt_auto

@@ -11,7 +11,7 @@ in-harness stubs:
 Noise is injected by patching ``torch.rand_like`` with the Philox stream of oracle/philox.py, so
 the same uniforms can be regenerated on the device (no noise tensors are stored).
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [fixture names]
 """
 import os
 import sys
@@ -25,6 +25,7 @@ sys.path.insert(0, "/root/reference")
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from oracle import philox
 
@@ -239,22 +240,287 @@ def make_d3pm(name, K, L, spatial, n_layer, cond_dim, T, B, seed, noise_seed):
           "loop tokens unique:", len(np.unique(out["loop_tokens"])), "loss:", float(o["loss"]))
 
 
-def main():
+# --------------------------------------------------------------------------- generator glue (DiscreteDiffusion.forward)
+class TableTextEncoder(nn.Module):
+    """Stand-in for CLIPTextEmbedding in the fixture: a fixed (B, cond_dim) row per caption, stored in the fixture."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.table = table
+        self.dummy = nn.Parameter(torch.zeros(1))          # DiscreteDiffusion.__init__ reads next(self.parameters())
+
+    def forward(self, texts):
+        return torch.stack([self.table[t] for t in texts])
+
+
+def make_glue(name, vq_name, d3pm_name, seed):
+    """discrete_diffusion.py:16-83 run end to end (do_inference=True and False) on the two small fixture models: every key of the
+    output dict.  Two variants: as written (text embeddings zeroed, :25/:49) and with those two `zeros_like` calls made the identity
+    (the optional non-zero conditioning of SURVEY.md appendix D) -- the reference's code path otherwise untouched."""
+    import src.models.networks.discrete_diffusion as dd_mod
+    from src.models.networks.videogpt_vq_vae import VQVAE
+
+    zv = np.load(os.path.join(OUT, vq_name + ".npz"))
+    zd = np.load(os.path.join(OUT, d3pm_name + ".npz"))
+    cfgv = {k[4:]: (zv[k].tolist() if zv[k].ndim else zv[k].item()) for k in zv.files if k.startswith("cfg_")}
+    cfgd = {k[4:]: (zd[k].tolist() if zd[k].ndim else zd[k].item()) for k in zd.files if k.startswith("cfg_")}
+    vq = VQVAE(None, cfgv["embedding_dim"], cfgv["n_codes"], cfgv["n_hiddens"], cfgv["n_res_layers"], cfgv["downsample"],
+               cfgv["sequence_length"], cfgv["resolution"])
+    vq.load_state_dict({k[3:]: torch.from_numpy(zv[k]) for k in zv.files if k.startswith("sd/")})
+    vq.codebook._need_init = False
+    vq.eval()
+    K, L, T, B = cfgd["K"], cfgd["L"], cfgd["T"], cfgd["B"]
+    assert K == cfgv["n_codes"] and L == int(np.prod(vq.latent_shape))
+    dm = build_d3pm(K, L, cfgd["spatial"], cfgd["n_layer"], cfgd["cond_dim"], T, seed=0)
+    dm.load_state_dict({k[3:]: torch.from_numpy(zd[k]) for k in zd.files if k.startswith("sd/")}, strict=False)
+    dm.eval()
+    g = torch.Generator().manual_seed(seed)
+    texts = ["a person juggling", "waves on a beach"][:B]
+    table = {t: torch.randn(cfgd["cond_dim"], generator=g) for t in texts + [""]}
+    gen = dd_mod.DiscreteDiffusion.__new__(dd_mod.DiscreteDiffusion)
+    nn.Module.__init__(gen)
+    gen.textencoder = TableTextEncoder(table)
+    gen.diffusion_model = dm
+    x = torch.from_numpy(zv["x"])
+    batch = {"video": x, "text": texts, "length": [x.shape[2]] * B}
+    t_fix = torch.tensor([13, 0][:B], dtype=torch.long)
+    dm.sample_time = lambda b, device, method="uniform": (t_fix, torch.ones(b) / T)
+    out = {"cfg_vqvae": vq_name, "cfg_d3pm": d3pm_name, "cfg_noise_seed": cfgd["noise_seed"], "cfg_stream": 7000,
+           "texts": np.array(texts), "text_table": torch.stack([table[t] for t in texts + [""]]).numpy(), "t": t_fix.numpy()}
+    real_zeros_like = torch.zeros_like
+    sampled, real_sample = [], dm.sample
+
+    def sample_and_keep(*a, **k):                          # the sampled tokens, to make a decode mismatch diagnosable
+        r = real_sample(*a, **k)
+        sampled.append(r["content_token"].numpy().copy())
+        return r
+
+    dm.sample = sample_and_keep
+
+    def keep_text(x_, *a, **k):                            # the two text-embedding zeroings become the identity
+        if x_.dim() == 3 and x_.shape[1:] == (1, cfgd["cond_dim"]):
+            return x_.clone()
+        return real_zeros_like(x_, *a, **k)
+
+    for tag, zl in (("zero", real_zeros_like), ("cond", keep_text)):
+        torch.zeros_like = zl
+        dm.Lt_history.zero_(); dm.Lt_count.zero_()
+        torch.rand_like = PhiloxRand(cfgd["noise_seed"], stream0=7000)
+        with torch.no_grad():
+            o = gen(batch, vq, None, do_inference=True)
+        torch.zeros_like = real_zeros_like
+        assert set(o) == {"pred_data", "pred_single_step", "gt_data", "losses", "test"}
+        out.update({f"{tag}/pred_data": o["pred_data"].numpy(), f"{tag}/pred_single_step": o["pred_single_step"].numpy(),
+                    f"{tag}/losses": o["losses"].numpy(), f"{tag}/test": o["test"].numpy(), f"{tag}/content_token": sampled[-1],
+                    f"{tag}/Lt_history": dm.Lt_history.numpy().copy(), f"{tag}/Lt_count": dm.Lt_count.numpy().copy()})
+        torch.rand_like = PhiloxRand(cfgd["noise_seed"], stream0=7000)
+        dm.Lt_history.zero_(); dm.Lt_count.zero_()
+        torch.zeros_like = zl
+        with torch.no_grad():
+            o2 = gen(batch, vq, None)
+        torch.zeros_like = real_zeros_like
+        assert set(o2) == {"pred_data", "gt_data", "losses", "test"}
+        assert torch.equal(o2["pred_data"], o["pred_single_step"]) and torch.equal(o2["losses"], o["losses"])
+        print(name, tag, "loss", float(o["losses"]), "sampled-vs-gt mse", float(((o["pred_data"] - x) ** 2).mean()))
+    assert torch.equal(o["gt_data"], x)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+# --------------------------------------------------------------------------- near-tie stress vectors + sample_time
+def make_neartie(name, seed, noise_seed):
+    """Inputs built so that the reference's two arg-extrema decide on margins of 1e-7 ... 1e-3 (the regular fixtures' minimum
+    margins are 1e-3 / 1e-2, far above fp32 noise):
+      * Codebook.forward (videogpt_vq_vae.py:174-222, eval mode): latents placed next to the bisector of deliberately close code
+        pairs; recorded: the reference's indices, the fp64 margin d(z, 2nd)^2 - d(z, 1st)^2 and the fp64 winner;
+      * p_sample (diffusion_transformer.py:304-359) with the denoiser replaced by a table of logits: one conditional logit per
+        position is bisected until the top-2 gap of `gumbel + posterior` hits a target; recorded: the reference's sampled tokens,
+        the gap it saw (fp32) and the gap / winner of an fp64 evaluation of the same formulas.
+      * sample_time('importance') (:368-389) after every Lt_count passed 10: the reference's (t, pt) under torch.manual_seed."""
+    import src.models.motionencoder.diffusion_transformer as dt_mod
+    from src.models.networks.videogpt_vq_vae import Codebook
+    from oracle import d3pm as od
+
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    targets = torch.tensor([s * m for m in (1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 1e-3) for s in (1.0, -1.0)])
+
+    # ---- codebook
+    Kc, E = 32, 8
+    cb = torch.randn(Kc, E, generator=g) * 3.0
+    deltas = torch.tensor([1e-1, 1e-2, 1e-3, 1e-4])
+    z_rows, pairs = [], []
+    for i in range(64):
+        j = i % (Kc // 2)
+        d = torch.randn(E, generator=g)
+        d = d / d.norm()
+        if i < Kc // 2:
+            cb[2 * j + 1] = cb[2 * j] + deltas[j % 4] * d                 # a close pair
+        dirv = (cb[2 * j + 1] - cb[2 * j])
+        dist = dirv.norm()
+        mid = 0.5 * (cb[2 * j] + cb[2 * j + 1])
+        # margin = |z - b|^2 - |z - a|^2 = 2 eps dist for z = mid - eps * dir/|dir| (+ an offset orthogonal to dir)
+        eps = targets[i % len(targets)] / (2 * dist)
+        orth = torch.randn(E, generator=g) * 0.3
+        orth = orth - (orth @ dirv) / (dist * dist) * dirv
+        z_rows.append(mid - eps * dirv / dist + orth)
+        pairs.append((2 * j, 2 * j + 1))
+    z = torch.stack(z_rows).view(1, 4, 4, 4, E).permute(0, 4, 1, 2, 3).contiguous()        # (1,E,4,4,4)
+    book = Codebook(Kc, E)
+    book.embeddings.data.copy_(cb)
+    book._need_init = False
+    book.eval()
+    with torch.no_grad():
+        ref_idx = book(z)["encodings"].view(-1)
+    flat64 = z.permute(0, 2, 3, 4, 1).reshape(-1, E).double()
+    d64 = ((flat64[:, None, :] - cb.double()[None]) ** 2).sum(-1)
+    top2 = torch.topk(d64, 2, dim=1, largest=False)
+    out.update({"cb/z": z.numpy(), "cb/codebook": cb.numpy(), "cb/ref_idx": ref_idx.numpy(),
+                "cb/margin64": (top2.values[:, 1] - top2.values[:, 0]).numpy(), "cb/winner64": top2.indices[:, 0].numpy(),
+                "cb/second64": top2.indices[:, 1].numpy()})
+
+    # ---- Gumbel arg-max through p_sample with a logits table in place of the denoiser
+    K, L, T, B = 32, 16, 100, 4
+    dm = build_d3pm(K, L, [4, 4], 1, 32, T, seed=seed + 1)
+    lc = torch.randn(B, K, L, generator=g) * 1.5
+    lu = torch.randn(B, K, L, generator=g) * 1.5
+    cond = torch.ones(B, 1, 32)
+    cf_cond = torch.zeros(B, 1, 32)
+
+    class Table(nn.Module):
+        def forward(self, x_t, cond_emb, t):
+            return (lc if float(cond_emb.abs().sum()) > 0 else lu).clone()
+    dm.transformer = Table()
+    xt = torch.randint(0, K, (B, L), generator=g)
+    xt[torch.rand(B, L, generator=g) < 0.5] = K
+    t = torch.tensor([80, 40, 10, 0])
+    log_xt = dt_mod.index_to_log_onehot(xt, K + 1)
+    stream = 9000
+    u = torch.from_numpy(philox.uniform_bkl(noise_seed, stream, B, K + 1, L))
+    gum = -torch.log(-torch.log(u + 1e-30) + 1e-30)                       # the expression of log_sample_categorical, same ops
+
+    def scores():
+        with torch.no_grad():
+            post, _ = dm.p_pred(log_xt, cond, cf_cond, t)
+        return gum + post
+
+    sc = scores()
+    top1 = sc.argmax(1)
+    sc_codes = sc[:, :K].clone()
+    sc_codes.scatter_(1, top1.clamp(max=K - 1).unsqueeze(1), float("-inf"))           # best code other than the winner
+    k2 = torch.where(top1 == K, sc[:, :K].argmax(1), sc_codes.argmax(1))
+    tgt = targets[torch.arange(B * L) % len(targets)].view(B, L)
+    base = lc.gather(1, k2.unsqueeze(1)).squeeze(1).clone()
+    lo, hi = torch.full((B, L), -5.0), torch.full((B, L), 60.0)
+
+    def gap_at(shift):
+        lc.scatter_(1, k2.unsqueeze(1), (base + shift).unsqueeze(1))
+        sc = scores()
+        mine = sc.gather(1, k2.unsqueeze(1)).squeeze(1)
+        rest = sc.clone()
+        rest.scatter_(1, k2.unsqueeze(1), float("-inf"))
+        return mine - rest.max(1).values
+    for _ in range(60):                                                   # gap is increasing in the shift
+        mid = 0.5 * (lo + hi)
+        too_big = gap_at(mid) > tgt
+        hi = torch.where(too_big, mid, hi)
+        lo = torch.where(too_big, lo, mid)
+    gap_at(hi)
+    torch.rand_like = PhiloxRand(noise_seed, stream0=stream)
+    with torch.no_grad():
+        samp, _ = dm.p_sample(log_xt, cond, cf_cond, t, [0] * B, 0)
+    ref_tok = dt_mod.log_onehot_to_index(samp)
+    sc = scores()
+    t2 = torch.topk(sc, 2, dim=1)
+    assert torch.equal(sc.gather(1, ref_tok.unsqueeze(1)).squeeze(1), t2.values[:, 0])      # (exact fp32 ties: argmax = first index)
+    # fp64 evaluation of the same formulas on the same fp32 inputs
+    sd64 = {k: v.double() for k, v in dm.state_dict().items() if k.startswith("log_")}
+
+    def ps64(o):
+        lp = F.log_softmax(o.double(), dim=1).clamp(-70, 0)
+        return lp
+    mix = ps64(lu) + 2.0 * (ps64(lc) - ps64(lu))
+    mix = (mix - torch.logsumexp(mix, dim=1, keepdim=True)).clamp(-70, 0)
+    rec64 = torch.cat((mix, torch.full((B, 1, L), -70.0, dtype=torch.float64)), dim=1)
+    logxt64 = torch.log(F.one_hot(xt, K + 1).permute(0, 2, 1).double().clamp(min=1e-30))
+    post64 = q_posterior64(rec64, logxt64, t, sd64)
+    g64 = -torch.log(-torch.log(u.double() + 1e-30) + 1e-30)
+    s64 = g64 + post64
+    t64 = torch.topk(s64, 2, dim=1)
+    out.update({"gum/logits_c": lc.numpy(), "gum/logits_u": lu.numpy(), "gum/xt": xt.numpy(), "gum/t": t.numpy(),
+                "gum/stream": stream, "gum/ref_tok": ref_tok.numpy(), "gum/margin_ref": (t2.values[:, 0] - t2.values[:, 1]).numpy(),
+                "gum/margin64": (t64.values[:, 0] - t64.values[:, 1]).numpy(), "gum/winner64": t64.indices[:, 0].numpy(),
+                "gum/second64": t64.indices[:, 1].numpy(), "cfg_K": K, "cfg_L": L, "cfg_T": T, "cfg_B": B,
+                "cfg_noise_seed": noise_seed, "cfg_guidance": 2.0})
+    out.update(sd_to_np({k: v for k, v in dm.state_dict().items() if k.startswith("log_")}, "sd/"))
+
+    # ---- sample_time('importance') once every timestep has been visited more than 10 times
+    dm.Lt_count.fill_(11.0)
+    dm.Lt_history.copy_(torch.rand(T, generator=g) * 50.0 + 0.01)
+    torch.manual_seed(seed + 7)
+    t_imp, pt_imp = dm.sample_time(64, "cpu", "importance")
+    out.update({"st/Lt_history": dm.Lt_history.numpy().copy(), "st/seed": seed + 7, "st/t": t_imp.numpy(), "st/pt": pt_imp.numpy()})
+    dm.Lt_count[3] = 10.0                                                 # one timestep short: falls back to uniform
+    torch.manual_seed(seed + 8)
+    t_uni, pt_uni = dm.sample_time(64, "cpu", "importance")
+    out.update({"st/seed_uniform": seed + 8, "st/t_uniform": t_uni.numpy(), "st/pt_uniform": pt_uni.numpy()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "codebook |margin64| min/max:", float(np.abs(out["cb/margin64"]).min()), float(np.abs(out["cb/margin64"]).max()),
+          "ref==fp64:", int((out["cb/ref_idx"] == out["cb/winner64"]).sum()), "/ 64;",
+          "gumbel |margin64| min/max:", float(np.abs(out["gum/margin64"]).min()), float(np.abs(out["gum/margin64"]).max()),
+          "ref==fp64:", int((out["gum/ref_tok"] == out["gum/winner64"]).sum()), "/", B * L)
+
+
+def q_posterior64(log_x_start, log_x_t, t, sd):
+    """diffusion_transformer.py:251-283 in float64 (same formulas as oracle/d3pm.py::q_posterior, no fp32 constants)."""
+    B, K1, L = log_x_start.shape
+    lz = float(np.log(1e-30))
+    ext = lambda a, tt: a.gather(-1, tt).reshape(-1, 1, 1)
+    lae = lambda a, b: torch.max(a, b) + torch.log(torch.exp(a - torch.max(a, b)) + torch.exp(b - torch.max(a, b)))
+    T = sd["log_at"].shape[0]
+
+    def q_pred(lx, tt):
+        tt = (tt + (T + 1)) % (T + 1)
+        return torch.cat([lae(lx[:, :-1] + ext(sd["log_cumprod_at"], tt), ext(sd["log_cumprod_bt"], tt)),
+                          lae(lx[:, -1:] + ext(sd["log_1_min_cumprod_ct"], tt), ext(sd["log_cumprod_ct"], tt))], dim=1)
+
+    def q_one(lx, tt):
+        return torch.cat([lae(lx[:, :-1] + ext(sd["log_at"], tt), ext(sd["log_bt"], tt)),
+                          lae(lx[:, -1:] + ext(sd["log_1_min_ct"], tt), ext(sd["log_ct"], tt))], dim=1)
+    mask = (log_x_t.argmax(1) == K1 - 1).unsqueeze(1)
+    log_zero = torch.full((B, 1, L), lz, dtype=torch.float64)
+    log_qt = q_pred(log_x_t, t)[:, :-1]
+    log_qt = torch.where(mask, ext(sd["log_cumprod_ct"], t).expand(-1, K1 - 1, L), log_qt)
+    log_q1 = torch.cat((q_one(log_x_t, t)[:, :-1], log_zero), dim=1)
+    ct_vec = torch.cat((ext(sd["log_ct"], t).expand(-1, K1 - 1, L), torch.zeros(B, 1, L, dtype=torch.float64)), dim=1)
+    log_q1 = torch.where(mask, ct_vec, log_q1)
+    q = torch.cat((log_x_start[:, :-1] - log_qt, log_zero), dim=1)
+    s_ = torch.logsumexp(q, dim=1, keepdim=True)
+    q = q - s_
+    return torch.clamp(q_pred(q, t - 1) + log_q1 + s_, -70, 0)
+
+
+def main(argv):
+    """No arguments: every fixture.  Otherwise the named ones (vqvae_ds188 vqvae_ds244 d3pm_L64 vqvae_train_ds188 glue_L64 ...)."""
     install_stubs()
     real_rand_like = torch.rand_like
     os.makedirs(OUT, exist_ok=True)
-    make_vqvae("vqvae_ds188", dict(embedding_dim=8, n_codes=32, n_hiddens=16, n_res_layers=2,
-                                   downsample=[1, 8, 8], sequence_length=4, resolution=32), B=2, seed=11)
-    make_vqvae("vqvae_ds244", dict(embedding_dim=8, n_codes=24, n_hiddens=16, n_res_layers=1,
-                                   downsample=[2, 4, 4], sequence_length=4, resolution=16), B=1, seed=12)
-    make_d3pm("d3pm_L64", K=32, L=64, spatial=[8, 8], n_layer=2, cond_dim=32, T=100, B=2, seed=21,
-              noise_seed=1234)
+    jobs = {
+        "vqvae_ds188": lambda: make_vqvae("vqvae_ds188", dict(embedding_dim=8, n_codes=32, n_hiddens=16, n_res_layers=2,
+                                                              downsample=[1, 8, 8], sequence_length=4, resolution=32), B=2, seed=11),
+        "vqvae_ds244": lambda: make_vqvae("vqvae_ds244", dict(embedding_dim=8, n_codes=24, n_hiddens=16, n_res_layers=1,
+                                                              downsample=[2, 4, 4], sequence_length=4, resolution=16), B=1, seed=12),
+        "d3pm_L64": lambda: make_d3pm("d3pm_L64", K=32, L=64, spatial=[8, 8], n_layer=2, cond_dim=32, T=100, B=2, seed=21,
+                                      noise_seed=1234),
+        "vqvae_train_ds188": lambda: make_vqvae_train("vqvae_train_ds188", dict(embedding_dim=8, n_codes=32, n_hiddens=16,
+                                                                                n_res_layers=1, downsample=[1, 8, 8],
+                                                                                sequence_length=4, resolution=32), B=2, seed=31),
+        "glue_L64": lambda: make_glue("glue_L64", "vqvae_ds188", "d3pm_L64", seed=41),
+        "neartie": lambda: make_neartie("neartie", seed=51, noise_seed=4321),
+    }
+    for name in (argv or list(jobs)):
+        torch.rand_like = real_rand_like
+        jobs[name]()
     torch.rand_like = real_rand_like
-    make_vqvae_train("vqvae_train_ds188", dict(embedding_dim=8, n_codes=32, n_hiddens=16, n_res_layers=1,
-                                               downsample=[1, 8, 8], sequence_length=4, resolution=32), B=2, seed=31)
-
-
-
 
 
 # --------------------------------------------------------------------------- VQ-VAE train-mode forward
@@ -304,4 +570,4 @@ def make_vqvae_train(name, cfg, B, seed):
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -158,16 +158,24 @@ def _dp_worker(rank, world, port, q):
     torch.cuda.set_device(0)
     x, sd, cfg, perm = case(gsdd_amd, load_golden, "train_ds188")
     m = build_vqvae(gsdd_amd, sd, cfg)
+    if rank == 1:                                    # a rank that was seeded differently: the trainer's start-up broadcast
+        with torch.no_grad():                        # (rank 0 wins, as under DDP) must bring it back before the first step
+            for prm in m.parameters():
+                prm.add_(0.05 * torch.randn_like(prm))
+            m.codebook.embeddings.add_(0.3)
+        m._packed = None
     pt = torch.from_numpy(np.random.default_rng(7).permutation(64))     # one clip per rank: 64 latent rows
     m.perm_source = lambda n: pt
     tr = VQVAETrainer(m)
-    _, g = tr.loss_and_grads(x[rank:rank + 1].cuda())
-    g = tr.all_reduce_grads(g)
+    sv, _ = tr.forward(x[rank:rank + 1].cuda())
+    g = tr.backward(sv, 1.0, 1.0, reduce=True)       # bucketed all-reduce (decoder half, encoder half)
+    g = {k: v.clone() for k, v in g.items()}
+    perp = float(tr.last_perplexity)                 # of this rank's own latents (videogpt_vq_vae.py:218-219)
     tr2 = VQVAETrainer(build_vqvae(gsdd_amd, sd, cfg))
     tr2.vq.perm_source = lambda n: pt
     tr2.step(x[rank:rank + 1].cuda())                 # the full step (codebook collectives + all-reduce + Adam) must run
     cb = tr2.vq.codebook.embeddings.detach().cpu().numpy()
-    q.put((rank, {k: v.cpu().numpy() for k, v in g.items()}, cb))
+    q.put((rank, {k: v.cpu().numpy() for k, v in g.items()}, cb, perp, tr.reducer.last_buckets))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -181,11 +189,14 @@ def test_vqvae_two_rank_data_parallel_gradients(G, golden):
     from gsdd_amd.vqvae_trainer import VQVAETrainer
     x, sd, cfg, perm = case(G, golden, "train_ds188")
     pt = torch.from_numpy(np.random.default_rng(7).permutation(64))
-    per_rank = []
+    from oracle import vqvae as ov
+    per_rank, want_perp = [], []
     for r in range(2):
         m = build_vqvae(G, sd, cfg)
         m.perm_source = lambda n: pt
         per_rank.append(VQVAETrainer(m).loss_and_grads(x[r:r + 1].cuda())[1])
+        with torch.no_grad():                        # the oracle's perplexity of rank r's clip alone (the local one-hot mean)
+            want_perp.append(float(ov.forward_train(x[r:r + 1], sd, cfg, pt.numpy())[0]["perplexity"]))
     want = {k: 0.5 * (per_rank[0][k] + per_rank[1][k]).cpu() for k in per_rank[0]}
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -197,8 +208,10 @@ def test_vqvae_two_rank_data_parallel_gradients(G, golden):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for _, g, _ in res:
+    for r, g, _, perp, buckets in res:
         compare({k: torch.from_numpy(v) for k, v in g.items()}, want, tol=1e-4)
+        np.testing.assert_allclose(perp, want_perp[r], rtol=1e-5)
+        assert buckets == 2
     np.testing.assert_array_equal(res[0][2], res[1][2])
 
 

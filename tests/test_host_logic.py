@@ -34,22 +34,110 @@ def test_cpu_inputs_fail_loudly_without_fallback():
         m.decode(torch.zeros(1, 4, 4, 4, dtype=torch.long))
 
 
-def test_compose_and_instantiate_reference_targets():
+SMALL = ["batch_size=2", "datamodule.sequence_length=4", "datamodule.resolution=32"]
+
+
+def test_compose_and_instantiate_reference_targets(monkeypatch):
+    """configs/ mirrors the reference's tree (same group files, same defaults lists): `model=discrete_diffusion` composes through
+    model/motionencoder/{diffusion_transformer,transformer_utils,dalle_mask_image_embedding}.yaml, model/textencoder/*, model/
+    evaluator.yaml, callbacks/, paths/, hydra/ and instantiates through the reference's `_target_` strings."""
     import src  # noqa: F401
     from gsdd_amd.hydra_lite import compose, instantiate
-    cfg = compose(os.path.join(REPO, "configs"), "eval.yaml", ["batch_size=2", "datamodule.sequence_length=4",
-                                                                "datamodule.resolution=32",
-                                                                "model.generator.diffusion_model.transformer.n_layer=2"])
+    monkeypatch.setenv("PROJECT_ROOT", REPO)
+    cfg = compose(os.path.join(REPO, "configs"), "eval.yaml", SMALL + ["model.generator.diffusion_model.transformer.n_layer=2"])
     assert cfg.model._target_ == "src.models.multistage_text_motion_model.MultistageTextMotionModel"
     assert cfg.model.autoencoder.sequence_length == 4 and cfg.datamodule.batch_size == 2
+    assert cfg.model.generator.diffusion_model._target_ == "src.models.motionencoder.diffusion_transformer.DiffusionTransformer"
     assert cfg.model.generator.diffusion_model.transformer.dalle.num_embed == 4096
+    assert cfg.model.generator.textencoder._target_ == "src.models.text_models.clip_text_embedding.CLIPTextEmbedding"
+    assert cfg.model.evaluator._target_ == "src.utils.evaluator.Evaluator" and cfg.model.evaluator.checkpoint_paths == "__None__"
+    assert cfg.callbacks.model_checkpoint.monitor == "total/val" and cfg.callbacks.model_checkpoint.save_last is True
+    assert cfg.callbacks.model_checkpoint.dirpath.startswith(REPO) and cfg.callbacks.model_checkpoint.dirpath.endswith("/checkpoints")
+    assert cfg.trainer.default_root_dir == cfg.paths.output_dir and "/eval/runs/" in cfg.paths.output_dir
+    assert "hydra" not in cfg
     model = instantiate(cfg.model, _recursive_=False)
     assert type(model.autoencoder).__name__ == "VQVAE" and model.autoencoder.latent_shape == (4, 4, 4)
+    assert type(model.generator).__name__ == "DiscreteDiffusion" and model.generator.zero_text_emb is True
     tr = model.generator.diffusion_model.transformer
     assert len(tr.blocks) == 2 and tr.content_emb.num_embed == 4097
+    assert tuple(tr.blocks[0].ln1.emb.weight.shape) == (1000, 64)          # the reference leaves the transformer's diffusion_step at 1000
+    opts = model.configure_optimizers()
+    assert len(opts) == 2 and opts[0].defaults["lr"] == 1e-4 and opts[1].defaults["lr"] == 1e-6 and opts[0].defaults["betas"] == (0.5, 0.999)
+    assert not model.train().autoencoder.training and model.generator.training
     cfg1 = compose(os.path.join(REPO, "configs"), "train.yaml", ["model=videogpt_vq_vae"])
     m1 = instantiate(cfg1.model, _recursive_=False)
-    assert m1.generator.n_codes == 4096 and len(list(m1.configure_optimizers().param_groups)) == 1
+    o1, sched = m1.configure_optimizers()
+    assert m1.generator.n_codes == 4096 and len(o1) == 1 and sched == [] and o1[0].defaults["lr"] == 4e-4
+    dm = instantiate(compose(os.path.join(REPO, "configs"), "train.yaml", ["datamodule=msrvtt"] + SMALL).datamodule)
+    assert type(dm).__name__ == "MSRVTTDataModule" and dm.sequence_length == 4
+    with pytest.raises(NotImplementedError, match="do_evaluation"):
+        instantiate(cfg.model.evaluator, device="cpu", _recursive_=False)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="the reference tree only exists in the build container")
+def test_reference_config_tree_composes_and_instantiates_unchanged(monkeypatch):
+    """The reference's OWN configs/ (train.yaml + model=... as its job files pass it, vqvae.job:15, ucf-ddiff-train.job:15) through
+    hydra_lite and this build's `src.` modules: paths/hydra/now resolvers, callbacks' sibling defaults, nested `@package`
+    placement.  Only the evaluator (I3D weights) and the checkpoint path (a file on the authors' cluster) are switched off."""
+    import src  # noqa: F401
+    from gsdd_amd.hydra_lite import compose, instantiate
+    monkeypatch.setenv("PROJECT_ROOT", REPO)
+    ref = "/root/reference/configs"
+    cfg = compose(ref, "train.yaml", ["model=discrete_diffusion", "model.do_evaluation=false",
+                                      "model.checkpoint_paths.autoencoder=__None__"])
+    assert cfg.model.autoencoder.n_codes == 2048 and cfg.model.autoencoder.sequence_length == 4
+    assert cfg.model.generator.diffusion_model.diffusion_step == 50 and cfg.model.devices == [0]
+    assert cfg.callbacks.model_checkpoint.filename == "epoch_{epoch:03d}" and cfg.paths.datasets == "/home1/chemburk"
+    model = instantiate(cfg.model, _recursive_=False)
+    dmod = model.generator.diffusion_model
+    assert model.autoencoder.latent_shape == (2, 16, 16) and dmod.num_timesteps == 50 and dmod.num_classes == 2049
+    assert len(dmod.transformer.blocks) == 19 and dmod.guidance_scale == 2
+    # a reference-shaped stage-2 state_dict (dead attn2.mask buffers, 1000-row AdaLayerNorm tables) loads into it
+    from gsdd_amd.checkpoint import load_reference_checkpoint
+    sd = {"generator." + k: v.clone() for k, v in model.generator.state_dict().items()}
+    sd["generator.diffusion_model.transformer.blocks.3.attn2.mask"] = torch.ones(1, 1, 4, 4)
+    assert load_reference_checkpoint(model.generator, {"state_dict": sd}) == ["diffusion_model.transformer.blocks.3.attn2.mask"]
+    cfg1 = compose(ref, "train.yaml", ["model=videogpt_vq_vae", "model.do_evaluation=false"])
+    m1 = instantiate(cfg1.model, _recursive_=False)
+    assert m1.generator.downsample == [1, 16, 16] and m1.lr_args["gen_lr"] == 4e-4
+    assert compose(ref, "train.yaml", ["model=videogpt_vq_vae", "datamodule=msrvtt"]).datamodule._target_.endswith("MSRVTTDataModule")
+
+
+def test_compute_losses_accumulator_and_log_names():
+    """src/models/metrics/loss.py:29-60: update() returns the weighted sum with its graph, compute() the means, loss2logname."""
+    from src.models.metrics.loss import ComputeLosses
+    cl = ComputeLosses(loss_dict={"l_dummy": 2.0})
+    a = torch.tensor(3.0, requires_grad=True)
+    t1 = cl.update({"losses": a})                                         # stage 2: a scalar
+    t2 = cl.update({"losses": {"commitment_loss": torch.tensor(1.0), "recon_loss": torch.tensor(4.0)}})   # stage 1: a dict
+    assert t1.requires_grad and float(t1) == 6.0 and float(t2) == 10.0
+    out = cl.compute()
+    assert float(out["l_dummy"]) == 4.0 and float(out["total"]) == 8.0
+    assert cl.loss2logname("l_dummy", "val") == "l/dummy/val" and cl.loss2logname("total", "train") == "total/train"
+    cl.reset()
+    assert cl.count == 0
+    with pytest.raises(KeyError):
+        ComputeLosses(loss_dict={"l_codebook": 1.0})
+
+
+def test_stage1_export_survives_the_reference_ten_character_strip(tmp_path):
+    """multistage_text_motion_model.py:113-122 strips param_key[10:] from every key: a VQ-VAE exported as
+    lightning_state(generator=vq) reads back bare; the file also loads through load_reference_checkpoint."""
+    import gsdd_amd
+    from gsdd_amd.checkpoint import lightning_state, load_reference_checkpoint
+    torch.manual_seed(1)
+    vq = gsdd_amd.VQVAE(None, 8, 32, 16, 1, [1, 4, 4], 4, 16)
+    path = str(tmp_path / "stage1.ckpt")
+    torch.save(lightning_state(generator=vq), path)
+    state = torch.load(path, weights_only=True)["state_dict"]
+    stripped = {k[10:]: v for k, v in state.items()}                       # the reference's loop, verbatim in effect
+    assert set(stripped) == set(vq.state_dict())
+    dst = gsdd_amd.VQVAE(None, 8, 32, 16, 1, [1, 4, 4], 4, 16)
+    dst.load_state_dict(stripped)
+    dst2 = gsdd_amd.VQVAE(None, 8, 32, 16, 1, [1, 4, 4], 4, 16)
+    load_reference_checkpoint(dst2, path)
+    for k, v in vq.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v) and torch.equal(dst2.state_dict()[k], v)
 
 
 def test_state_dict_keys_match_reference(golden):
