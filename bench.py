@@ -73,7 +73,8 @@ def attention_roofline(dm, B, L, H, device, K, reps=3):
     traffic = None
     if (B2, L, H) == (32, 4096, 16):
         traffic = (2 * 82033.7 + 33294.3) * 1024      # profiles/r1_pmc_traffic.csv, d3pm_attention_v4_kernel<384>
-    return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel", "achieved": round(tf, 2),
+    return {"bound": "mfma", "kernel": "d3pm_attention_v4_kernel" + ("<P11>" if os.environ.get("GSDD_ATTN_P") == "11" else ""),
+            "achieved": round(tf, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "ms_per_launch": round(ms, 4), "launches_timed": len(events), "flops_per_launch": flops}
 
@@ -107,6 +108,21 @@ def cpu_baseline(args, dm, vq, L):
                       "torch-CPU oracle"}
 
 
+def trained_like_weights(dm, seed=1):
+    """The `scale_weights` recipe of tests/test_gpu_fullsize.py::full_d3pm: weights of a trained-like magnitude (Linear ~
+    N(0, 1/fan_in), biases 0.1 N(0,1), embeddings 0.5 N(0,1)) instead of the reference's N(0, 0.02) init, under which the softmax
+    rows are nearly flat.  The attention kernel's cost is data-dependent only through its overflow-redo branch."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in dm.transformer.modules():
+            if isinstance(mod, torch.nn.Linear):
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * (1.0 / mod.in_features ** 0.5))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+            elif isinstance(mod, torch.nn.Embedding):
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * 0.5)
+    dm.transformer._packed = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,20 +136,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches of the sampler (separate HIP streams)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side regimes (trained-like weights, zero cond)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("GSDD_DIST_BACKEND", "nccl")          # "gloo" only to rehearse N>1 on a 1-GPU box
-    if os.environ.get("GSDD_FORCE_DEVICE") is not None:
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
+              f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` (one process per GPU)", file=sys.stderr)
+    if os.environ.get("GSDD_FORCE_DEVICE") is not None:            # rehearsal: several ranks on one card
         local = int(os.environ["GSDD_FORCE_DEVICE"])
+        os.environ["LOCAL_RANK"] = str(local)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK {local} but {torch.cuda.device_count()} GPU(s) visible: one process per GPU is the layout")
+    torch.cuda.set_device(local)                                   # before any allocation and before the process group exists
     if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend)
+        from gsdd_amd.parallel import init_distributed
+        init_distributed(backend)                                  # raises with the rendezvous it tried if the backend cannot start
     device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
 
     dm, vq, L = build_models(args, device)
     B = args.batch
@@ -158,18 +182,24 @@ def main():
     for _ in range(args.warmup):
         clips = one_pass()
     barrier()
+    from gsdd_amd import ops as _ops
+    _ops.d3pm_attention_redo_count(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         clips = one_pass()
     barrier()
     dt = time.perf_counter() - t0
+    headline_redo = _ops.d3pm_attention_redo_count(reset=True) / max(args.steps, 1)
     assert tuple(clips.shape) == (B, 3, args.grid[0], args.grid[1] * 8, args.grid[2] * 8)
     assert torch.isfinite(clips).all()
+    rank_s = [dt]
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+        tt = torch.zeros(world, device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        tt[rank] = dt
+        dist.all_reduce(tt)                                         # every rank's own time (sum of one-hot rows)
+        rank_s = tt.tolist()
+        dt = max(rank_s)
 
     if rank == 0:
         value = B * world * args.steps / dt
@@ -183,7 +213,12 @@ def main():
                                    f"{args.layers} layers, bs {B}/GPU + VQ-VAE decode to 3x{args.grid[0]}x"
                                    f"{args.grid[1] * 8}x{args.grid[2] * 8}",
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
-                       "hipgraph": not args.no_graph},
+                       "hipgraph": not args.no_graph,
+                       "arith": "f32 results; GEMM / QK^T operands as error-free 3-way bf16 splits on the matrix pipe (dropped terms "
+                                "< 2^-24); softmax P as f16 hi+lo (22 bits)" + (" -- THIS RUN: GSDD_ATTN_P=11, hi only (11 bits)"
+                                                                                 if os.environ.get("GSDD_ATTN_P") == "11" else "")},
+            "ranks": {"seconds_max": round(max(rank_s), 4), "seconds_min": round(min(rank_s), 4),
+                      "videos_per_s_per_rank": [round(B * args.steps / s_, 4) for s_ in rank_s]},
         }
         # the two side measurements must never cost the run its JSON line
         try:
@@ -195,6 +230,34 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args, dm, vq, L)
             except Exception as e:                               # noqa: BLE001
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_extra:
+            # regimes the dominant kernel could be sensitive to, outside the timed headline (same process, one warm + one timed
+            # pass each): the reference-faithful zero conditioning, and weights of a trained-like magnitude (peaky softmax rows);
+            # redo_chunks = overflow-redo events of the attention kernel per timed pass
+            try:
+                from gsdd_amd import ops
+
+                def timed(cond_):
+                    nonlocal cond
+                    keep, cond = cond, cond_
+                    one_pass()
+                    torch.cuda.synchronize()
+                    ops.d3pm_attention_redo_count(reset=True)
+                    t1 = time.perf_counter()
+                    one_pass()
+                    torch.cuda.synchronize()
+                    d = time.perf_counter() - t1
+                    cond = keep
+                    return round(B / d, 4), ops.d3pm_attention_redo_count(reset=True)
+                extra = {}
+                extra["zero_cond"], extra["redo_chunks_zero_cond"] = timed(torch.zeros_like(cond))
+                trained_like_weights(dm)
+                extra["trained_like"], extra["redo_chunks_trained_like"] = timed(cond)
+                extra["unit"] = "videos/s"
+                extra["redo_chunks_headline"] = headline_redo
+                line["extra"] = extra
+            except Exception as e:                               # noqa: BLE001
+                line["extra"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

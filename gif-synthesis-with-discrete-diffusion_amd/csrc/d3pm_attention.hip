@@ -317,6 +317,19 @@ __device__ __forceinline__ void split_p8(const float (&p)[8], uint4& hi, uint4& 
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
 }
 
+// hi part only (the "P11" variant: 11 significant bits of every probability instead of 22; the row sum comes from the SAME
+// rounded values through the ones column, so the weights still sum to one exactly).
+__device__ __forceinline__ void round_p8(const float (&p)[8], uint4& hi) {
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_cvt_pk_f16_f32 %2, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %3, %10, %11\n\t"
+        "s_nop 1"
+        : "=&v"(hi.x), "=&v"(hi.y), "=&v"(hi.z), "=&v"(hi.w)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
+}
+
 // Pre-split K and V once per (b,h) into the exact LDS images the attention workgroups consume (16 query blocks
 // share them), so staging inside the attention kernel is a plain copy:
 //   Kp[row][2] uint4 : pieces A=[k1|k2], B=[k3|k1] (bf16), slots swapped for (key&15)>=8
@@ -333,7 +346,14 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
     kv_image_store_v(vs, row, vp);
 }
 
-template <int KC4>
+// Diagnostic: how often the rare "accumulator overflowed, redo this chunk with a larger exponent offset" branch ran (one count per
+// workgroup and redo attempt).  The kernel's cost depends on the data through that branch only; bench.py reports the count per pass.
+__device__ unsigned long long g_attn_redo_events = 0ull;
+
+// LO = true: P = hi + lo (22 bits, the parity default).  LO = false: P = hi (11 bits): 12 of the 16 split instructions and one
+// of the two P.V MFMAs per 512 scores go away; the error this costs is measured in tests/test_gpu_attention_variants.py and
+// tabled in DESIGN.md -- selected only by GSDD_ATTN_P=11.
+template <int KC4, bool LO = true>
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
                                                                 const uint4* __restrict__ vp, int B, int L, int H,
                                                                 float* __restrict__ out, float* __restrict__ lse) {
@@ -445,9 +465,14 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(s0[r]); p[4 + r] = __builtin_amdgcn_exp2f(s1[r]); }
                     uint4 hi, lo;
-                    split_p8(p, hi, lo);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
+                    if (LO) {
+                        split_p8(p, hi, lo);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
+                    } else {
+                        round_p8(p, hi);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
+                    }
                 }
             }
             // overflow screen (f16 hi part saturated to inf somewhere in this chunk): rare
@@ -457,6 +482,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
             for (int j = 0; j < 4; ++j) chk += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
             const bool bad = !(fabsf(chk) < 3.0e38f);
             if (!__any(bad)) break;
+            if (lane == 0) atomicAdd(&g_attn_redo_events, 1ull);
             // rare path: exact maximum of this chunk's scores per query (relative to the current m), then move m so that
             // the chunk maximum lands in (2^2, 2^3]; accumulators restart from the chunk-start copy scaled by 2^-delta.
             float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -542,6 +568,13 @@ __global__ void d3pm_cross_attention_kernel(const float* q, const float* kc, con
 
 using namespace gsdd;
 
+// A/B switch of the sampler's attention arithmetic: GSDD_ATTN_P=11 -> P carried as one f16 (hi only); default 22 (hi + lo).
+// Read on every call (cheap) so that one process can measure both.
+static int attn_p_bits() {
+    const char* e = getenv("GSDD_ATTN_P");
+    return (e != nullptr && atoi(e) == 11) ? 11 : 22;
+}
+
 extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
     return (int64_t)B * L * H * 64;          // 32 B (K pieces) + 32 B (V image) per key and head
 }
@@ -571,12 +604,26 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
             GSDD_CHECK_LAUNCH();
         }
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
+        const int pbits = attn_p_bits();
         if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        else if (pbits == 11) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, false>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
         else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);
     }
     GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_d3pm_attention_redo_count(uint64_t* count, int reset) {
+    GSDD_CHECK_ARG(count != nullptr, "null pointer");
+    unsigned long long v = 0ull;
+    GSDD_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_redo_events), sizeof(v)));      // synchronises with the device
+    *count = (uint64_t)v;
+    if (reset) {
+        const unsigned long long z = 0ull;
+        GSDD_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_redo_events), &z, sizeof(z)));
+    }
     return GSDD_OK;
 }
 

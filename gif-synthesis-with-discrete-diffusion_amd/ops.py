@@ -173,6 +173,13 @@ def d3pm_attention(q, k, v, B, L, H, out, ws=None, stream=None):
     return out
 
 
+def d3pm_attention_redo_count(reset=False):
+    """Redo events of the matrix-pipe attention kernel since the last reset (synchronises)."""
+    n = C.c_uint64()
+    check(lib().gsdd_d3pm_attention_redo_count(C.byref(n), int(reset)))
+    return int(n.value)
+
+
 def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, stream=None):
     """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given).
     y = lay = None: only the next-block stage on x as it is (block 0, whose input is the embedding)."""

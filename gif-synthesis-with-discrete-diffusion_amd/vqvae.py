@@ -403,7 +403,9 @@ class VQVAE(nn.Module):
         if d < self.n_codes:
             n_repeats = (self.n_codes + d - 1) // d
             x = x.repeat(n_repeats, 1)
-            x = x + torch.randn_like(x) * (0.01 / math.sqrt(ew))
+            src = getattr(self, "noise_source", None)          # tests inject the jitter (a callable shape -> tensor)
+            noise = src(tuple(x.shape)).to(x) if src is not None else torch.randn_like(x)
+            x = x + noise * (0.01 / math.sqrt(ew))
         return x
 
     def _draw_rows(self, z):

@@ -167,6 +167,10 @@ int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H);
 /* k = v = NULL: the workspace already holds the K / V images (written by gsdd_d3pm_layer through kv_img). */
 int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
                         float* out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Diagnostic counter of the matrix-pipe attention kernel: number of (wave, chunk) redo events since the last reset -- the
+ * branch that restarts a 384-key chunk with a larger exponent offset after an f16 accumulator overflow; it is the only
+ * data-dependent cost of the kernel (0 for near-uniform attention).  Synchronises with the device. */
+int gsdd_d3pm_attention_redo_count(uint64_t* count, int reset);
 
 /* Fused post-attention half of a denoiser block (n_embd 64, hidden 256), rows updated in place:
  *   x += proj(y)+b_proj+cvec[b];  x += W2 GELU2(W1 LN2(x)+b1)+b2;  [qkv_next = Wqkv AdaLN_next(x,t)+b_qkv, head-major]

@@ -199,8 +199,9 @@ def p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream, first=False, n
     return gumbel_argmax(post, seed, stream, row0=row0), post
 
 
-def sample(B, L, cond, cf_cond, sd, scale, seed, n_head=16, trace=None, row0=0, steps=None):
-    """Reference: DiffusionTransformer.sample with filter_ratio=0, diffusion_transformer.py:568-644."""
+def sample(B, L, cond, cf_cond, sd, scale, seed, n_head=16, trace=None, row0=0, steps=None, stream0=0):
+    """Reference: DiffusionTransformer.sample with filter_ratio=0, diffusion_transformer.py:568-644.  Reverse step i draws
+    Philox stream `stream0 + i`."""
     T = sd["log_at"].shape[0]
     K1 = sd["transformer.content_emb.emb.weight"].shape[0]
     tok = torch.full((B, L), K1 - 1, dtype=torch.long)
@@ -208,7 +209,7 @@ def sample(B, L, cond, cf_cond, sd, scale, seed, n_head=16, trace=None, row0=0, 
         if steps is not None and i >= steps:
             break
         t = torch.full((B,), step, dtype=torch.long)
-        tok, _ = p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream=i, first=(i == 0), n_head=n_head,
+        tok, _ = p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream=stream0 + i, first=(i == 0), n_head=n_head,
                                row0=row0)
         if trace is not None:
             trace.append(tok.clone())

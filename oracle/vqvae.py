@@ -10,6 +10,7 @@ All functions take ``sd``: a dict name -> torch.Tensor with the reference's stat
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -188,10 +189,31 @@ def _res_stack_train(x, sd, p, n, out_sd):
     return F.relu(bn_train(x, sd, f"{p}{n}.", out_sd))
 
 
-def forward_train(x, sd, cfg, perm):
-    """Reference: VQVAE.forward with self.training (videogpt_vq_vae.py:58-72) and Codebook.forward's EMA branch
-    (:193-214) for an already-initialised codebook; `perm` replaces torch.randperm (:206).  Returns the output dict
-    and the updated buffers (same names as the state_dict)."""
+def tile(flat, n_codes, noise=None):
+    """Reference: Codebook._tile, videogpt_vq_vae.py:151-158: with fewer latents than codes the rows are repeated
+    ceil(n_codes / d) times and jittered by N(0, (0.01 / sqrt(E))^2); `noise` (tiled shape) replaces torch.randn_like."""
+    d, ew = flat.shape
+    if d < n_codes:
+        n_repeats = (n_codes + d - 1) // d
+        std = 0.01 / np.sqrt(ew)
+        flat = flat.repeat(n_repeats, 1)
+        assert noise is not None and tuple(noise.shape) == tuple(flat.shape), "tiling draws noise: inject it"
+        flat = flat + noise * std
+    return flat
+
+
+def init_embeddings(flat, n_codes, perm, noise=None):
+    """Reference: Codebook._init_embeddings, videogpt_vq_vae.py:160-172 -> (embeddings, z_avg, N)."""
+    y = tile(flat, n_codes, noise)
+    k_rand = y[torch.as_tensor(perm).long()][:n_codes]
+    return k_rand.clone(), k_rand.clone(), torch.ones(n_codes)
+
+
+def forward_train(x, sd, cfg, perm, init_perm=None, init_noise=None, noise=None):
+    """Reference: VQVAE.forward with self.training (videogpt_vq_vae.py:58-72) and Codebook.forward (:174-222):
+    data-init of the codebook first when `init_perm` is given (_need_init, :176-177), then the EMA branch (:193-214);
+    `perm` / `init_perm` replace torch.randperm (:206, :165), `noise` / `init_noise` the randn_like of _tile.
+    Returns the output dict and the updated buffers (same names as the state_dict)."""
     new = {}
     h = x
     for i, s in enumerate(conv_strides(cfg["downsample"])):
@@ -201,20 +223,22 @@ def forward_train(x, sd, cfg, perm):
     z = same_pad_conv3d(h, sd["pre_vq_conv.conv.weight"], sd["pre_vq_conv.conv.bias"], (1, 1, 1))
     E = sd["codebook.embeddings"]
     K = E.shape[0]
-    idx, _ = nearest_code(z, E)
     flat = z.permute(0, 2, 3, 4, 1).reshape(-1, z.shape[1])
+    N0, zavg0 = sd["codebook.N"], sd["codebook.z_avg"]
+    if init_perm is not None:
+        E, zavg0, N0 = init_embeddings(flat.detach(), K, init_perm, init_noise)
+    idx, _ = nearest_code(z, E)
     emb = F.embedding(idx, E).permute(0, 4, 1, 2, 3).contiguous()
     commitment = 0.25 * F.mse_loss(z, emb.detach())                   # :190
     onehot = F.one_hot(idx.view(-1), K).type_as(flat)
     n_total = onehot.sum(dim=0)
     encode_sum = flat.t() @ onehot
-    N = sd["codebook.N"] * 0.99 + 0.01 * n_total
-    z_avg = sd["codebook.z_avg"] * 0.99 + 0.01 * encode_sum.t()
+    N = N0 * 0.99 + 0.01 * n_total
+    z_avg = zavg0 * 0.99 + 0.01 * encode_sum.t()
     n = N.sum()
     weights = (N + 1e-7) / (n + K * 1e-7) * n
     newE = z_avg / weights.unsqueeze(1)
-    assert flat.shape[0] >= K, "tiling branch (_tile, :151-158) is not restated"
-    k_rand = flat[torch.from_numpy(perm).long()][:K]
+    k_rand = tile(flat.detach(), K, noise)[torch.as_tensor(perm).long()][:K]
     usage = (N.view(K, 1) >= 1).float()
     newE = newE * usage + k_rand * (1 - usage)
     new.update({"codebook.N": N, "codebook.z_avg": z_avg, "codebook.embeddings": newE})

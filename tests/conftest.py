@@ -34,3 +34,32 @@ def golden():
         return cache[name]
 
     return get
+
+
+def parity_report(name, record):
+    """Append one measured-parity record (mismatch counts, minimum margins, achieved errors) to the JSON the GPU tests leave
+    behind: $GSDD_PARITY_REPORT, default gpurun_out/parity_report.json (the directory gpurun copies back; the file is then
+    committed as profiles/rN_parity_report.json).  Also printed, so `pytest -s` / the captured log shows the numbers."""
+    import json
+    path = os.environ.get("GSDD_PARITY_REPORT", os.path.join(REPO, "gpurun_out", "parity_report.json"))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                data = json.load(f)
+        except Exception:
+            data = {}
+
+    def plain(v):
+        if isinstance(v, (np.floating, np.integer)):
+            return v.item()
+        if torch.is_tensor(v) or isinstance(v, np.ndarray):
+            return plain(v.tolist()) if getattr(v, "ndim", 1) else v.item()
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        return v
+    data[name] = {k: plain(v) for k, v in record.items()}
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+    print(f"[parity] {name}: " + ", ".join(f"{k}={data[name][k]}" for k in sorted(data[name])))

@@ -499,6 +499,56 @@ def q_posterior64(log_x_start, log_x_t, t, sd):
     return torch.clamp(q_pred(q, t - 1) + log_q1 + s_, -70, 0)
 
 
+# --------------------------------------------------------------------------- VQ-VAE first training step: codebook data-init
+def make_vqvae_init(name, cfg, B, seed):
+    """The very first train-mode forward of a fresh VQVAE: Codebook._init_embeddings (videogpt_vq_vae.py:160-172) and, with fewer
+    latents than codes, _tile's repeat + jitter (:151-158) -- in the init AND in the restart draw of the same step.  Captured:
+    both permutations (torch.randperm) and both noise tensors (torch.randn_like)."""
+    from src.models.networks.videogpt_vq_vae import VQVAE
+
+    torch.manual_seed(seed)
+    m = VQVAE(None, cfg["embedding_dim"], cfg["n_codes"], cfg["n_hiddens"], cfg["n_res_layers"],
+              cfg["downsample"], cfg["sequence_length"], cfg["resolution"])
+    g = torch.Generator().manual_seed(seed + 1)
+    shape = (B, 3, cfg["sequence_length"], cfg["resolution"], cfg["resolution"])
+    perms, noises = [], []
+    real_randperm, real_randn_like = torch.randperm, torch.randn_like
+
+    def cap_randperm(n, *a, **k):
+        p = real_randperm(n, generator=g)
+        perms.append(p.numpy().copy())
+        return p
+
+    def cap_randn_like(x, *a, **k):
+        r = torch.randn(x.shape, generator=g, dtype=x.dtype)
+        noises.append(r.numpy().copy())
+        return r
+
+    torch.randperm, torch.randn_like = cap_randperm, cap_randn_like
+    m.train()
+    assert m.codebook._need_init
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(shape, generator=g)
+    with torch.no_grad():
+        out = m({"video": x})
+    torch.randperm, torch.randn_like = real_randperm, real_randn_like
+    n_lat = B * int(np.prod(m.latent_shape))
+    assert len(perms) == 2 and len(noises) == (2 if n_lat < cfg["n_codes"] else 0), (len(perms), len(noises), n_lat)
+    res = {}
+    res.update(sd_to_np(before, "sd/"))
+    res.update(sd_to_np(m.state_dict(), "after/"))
+    res.update({"x": x.numpy(), "perm_init": perms[0], "perm": perms[1], "pred": out["pred_data"].numpy(),
+                "recon_loss": out["losses"]["recon_loss"].numpy(), "commitment_loss": out["losses"]["commitment_loss"].numpy(),
+                "cfg_embedding_dim": cfg["embedding_dim"], "cfg_n_codes": cfg["n_codes"],
+                "cfg_n_hiddens": cfg["n_hiddens"], "cfg_n_res_layers": cfg["n_res_layers"],
+                "cfg_downsample": np.array(cfg["downsample"]), "cfg_sequence_length": cfg["sequence_length"],
+                "cfg_resolution": cfg["resolution"]})
+    if noises:
+        res.update({"noise_init": noises[0], "noise": noises[1]})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    print(name, "latents:", n_lat, "codes:", cfg["n_codes"], "tiled:", bool(noises), "codes with N >= 1:", int((m.codebook.N >= 1).sum()))
+
+
 def main(argv):
     """No arguments: every fixture.  Otherwise the named ones (vqvae_ds188 vqvae_ds244 d3pm_L64 vqvae_train_ds188 glue_L64 ...)."""
     install_stubs()
@@ -516,6 +566,12 @@ def main(argv):
                                                                                 sequence_length=4, resolution=32), B=2, seed=31),
         "glue_L64": lambda: make_glue("glue_L64", "vqvae_ds188", "d3pm_L64", seed=41),
         "neartie": lambda: make_neartie("neartie", seed=51, noise_seed=4321),
+        # 16 latents < 24 codes: _tile repeats and jitters; 128 latents >= 32 codes: plain permutation draw
+        "vqvae_init_tiled": lambda: make_vqvae_init("vqvae_init_tiled", dict(embedding_dim=8, n_codes=24, n_hiddens=16, n_res_layers=1,
+                                                                            downsample=[1, 8, 8], sequence_length=4, resolution=16),
+                                                    B=1, seed=61),
+        "vqvae_init": lambda: make_vqvae_init("vqvae_init", dict(embedding_dim=8, n_codes=32, n_hiddens=16, n_res_layers=1,
+                                                                 downsample=[1, 8, 8], sequence_length=4, resolution=32), B=2, seed=62),
     }
     for name in (argv or list(jobs)):
         torch.rand_like = real_rand_like

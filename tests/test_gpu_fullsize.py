@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import parity_report
+
 pytestmark = pytest.mark.gpu
 
 
@@ -33,8 +35,28 @@ def full_d3pm(G, seed, scale_weights):
     return dm.eval()
 
 
+def _oracle_step(od, tok, cond, t, sd, seed, stream, K):
+    """One guided reverse step of the oracle at full size -> (tokens, fp32 top-2 margin of the Gumbel scores, logits c / u)."""
+    from oracle import philox
+    B, L = tok.shape
+    with torch.no_grad():
+        want_c = od.denoiser(tok, cond, t, sd)
+        want_u = od.denoiser(tok, torch.zeros_like(cond), t, sd)
+        log_xt = od.index_to_log_onehot(tok, K + 1)
+        rec = od.cf_mix(od.predict_start_from_logits(want_c)[:, :-1], od.predict_start_from_logits(want_u)[:, :-1], 2.0)
+        post = od.q_posterior(rec, log_xt, t, sd)
+        u = torch.from_numpy(philox.uniform_bkl(seed, stream, B, K + 1, L))
+        noisy = -torch.log(-torch.log(u + 1e-30) + 1e-30) + post
+        top2 = torch.topk(noisy, 2, dim=1).values
+    return noisy.argmax(1), (top2[:, 0] - top2[:, 1]), want_c, want_u
+
+
 @pytest.mark.parametrize("scale_weights", [False, True])
 def test_full_size_denoiser_logits_and_step(G, scale_weights):
+    """L = 4096, K = 4096, 19 layers, both weight scales: logits within 1e-4 of the oracle, and a teacher-forced chain of THREE
+    guided reverse steps (the oracle's tokens of step s feed step s+1 on both sides, so one flipped arg-max cannot hide the next
+    steps): a token may differ from the oracle's only where the oracle's own top-2 margin is below 1e-5 -- the measured counts,
+    margins and errors go to the parity report."""
     from oracle import d3pm as od
     dm = full_d3pm(G, 0, scale_weights)
     sd = {k: v.detach().clone() for k, v in dm.state_dict().items()}
@@ -43,30 +65,26 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
     tok = torch.randint(0, K, (B, L), generator=g)
     tok[torch.rand(B, L, generator=g) < 0.5] = K
     cond = torch.randn(B, 1, 512, generator=g)
-    t = torch.tensor([41])
-    with torch.no_grad():
-        want_c = od.denoiser(tok, cond, t, sd)
-        want_u = od.denoiser(tok, torch.zeros_like(cond), t, sd)
     dm = dm.cuda()
-    got = dm.transformer(tok.cuda(), cond.cuda(), t.cuda()).cpu()
-    err = (got - want_c).abs().max().item()
-    assert err < 1e-4, f"full-size logits differ by {err}"
-    # one guided reverse step from the oracle's logits math vs the device (tokens: exact except at near-ties)
     dm.set_noise(77)
-    out = dm.p_sample_tokens(tok.cuda(), cond.cuda(), torch.zeros_like(cond).cuda(), t.cuda(), 3).cpu()
-    with torch.no_grad():
-        log_xt = od.index_to_log_onehot(tok, K + 1)
-        rec = od.cf_mix(od.predict_start_from_logits(want_c)[:, :-1], od.predict_start_from_logits(want_u)[:, :-1], 2.0)
-        post = od.q_posterior(rec, log_xt, t, sd)
-        from oracle import philox
-        u = torch.from_numpy(philox.uniform_bkl(77, 3, B, K + 1, L))
-        noisy = -torch.log(-torch.log(u + 1e-30) + 1e-30) + post
-        want_tok = noisy.argmax(1)
-        top2 = torch.topk(noisy, 2, dim=1).values
-        margin = (top2[:, 0] - top2[:, 1])
-    mism = out != want_tok
-    assert not (mism & (margin > 1e-3)).any(), "token differs away from a near-tie"
-    assert mism.sum().item() <= 2, f"{mism.sum().item()} of {L} tokens differ"
+    rec = {"steps": [], "logits_err": [], "logits_err_uncond": [], "mismatches": [], "min_margin": [], "mismatch_margins": []}
+    for s, step in enumerate((41, 40, 39)):
+        t = torch.tensor([step])
+        want_tok, margin, want_c, want_u = _oracle_step(od, tok, cond, t, sd, 77, 3 + s, K)
+        got_c = dm.transformer(tok.cuda(), cond.cuda(), t.cuda()).cpu()
+        got_u = dm.transformer(tok.cuda(), torch.zeros_like(cond).cuda(), t.cuda()).cpu()
+        err_c, err_u = (got_c - want_c).abs().max().item(), (got_u - want_u).abs().max().item()
+        out = dm.p_sample_tokens(tok.cuda(), cond.cuda(), torch.zeros_like(cond).cuda(), t.cuda(), 3 + s).cpu()
+        mism = out != want_tok
+        rec["steps"].append(step); rec["logits_err"].append(err_c); rec["logits_err_uncond"].append(err_u)
+        rec["mismatches"].append(int(mism.sum())); rec["min_margin"].append(margin.min().item())
+        rec["mismatch_margins"].append(margin[mism].tolist())
+        tok = want_tok                                                   # teacher forcing: both sides continue from the oracle's tokens
+    parity_report(f"full_size_d3pm_chain[scale_weights={scale_weights}]", rec)
+    assert max(rec["logits_err"] + rec["logits_err_uncond"]) < 1e-4, rec
+    for margins in rec["mismatch_margins"]:
+        assert all(m < 1e-5 for m in margins), f"token differs away from a near-tie: {rec}"
+    assert sum(rec["mismatches"]) == 0, f"tokens differ (all at near-ties, margins {rec['mismatch_margins']})"
 
 
 @pytest.mark.parametrize("res", [128, 64])      # C2's clip shape, and config C1 (one 16x64x64 clip, encode -> quantise -> decode)
@@ -99,17 +117,22 @@ def test_full_size_vqvae_encode_decode(G, res):
     m = m.cuda()
     z, dims = m._encode_rows(x.cuda())
     zerr = (z.cpu() - flat).abs().max().item()
-    assert zerr < 2e-4, zerr
     idx = m.encode(x.cuda()).cpu()
     top2 = torch.topk(d, 2, dim=1, largest=False).values
     margin = (top2[:, 1] - top2[:, 0])
     mism = (idx != idx_ref).view(-1)
-    assert not (mism & (margin > 1e-3)).any()
-    assert mism.sum().item() <= 4, f"{mism.sum().item()} of {mism.numel()} code indices differ"
     rec = m.decode(idx_ref.cuda()).cpu()
     assert tuple(rec.shape) == (1, 3, 16, res, res)
     rerr = (rec - rec_ref).abs().max().item()
-    assert rerr < 2e-4, rerr
+    parity_report(f"full_size_vqvae[res={res}]", {"latent_err": zerr, "latent_scale": flat.abs().max().item(), "decode_err": rerr,
+                                                   "code_mismatches": int(mism.sum()), "codes": mism.numel(),
+                                                   "min_margin": margin.min().item(), "mismatch_margins": margin[mism].tolist()})
+    assert zerr < 1e-4, zerr
+    # a code index may differ from the oracle's only where the oracle's own fp32 distances are a near-tie: the distances are
+    # ~|z|^2 + |e|^2 ~ 1e2..1e3 here, one fp32 ulp of that is ~3e-5
+    assert all(mm < 2e-4 for mm in margin[mism].tolist()), margin[mism].tolist()
+    assert mism.sum().item() == 0, f"{mism.sum().item()} of {mism.numel()} code indices differ (margins {margin[mism].tolist()})"
+    assert rerr < 1e-4, rerr
     # property: decode is batch-independent and deterministic
     rec2 = m.decode(torch.cat([idx_ref, idx_ref.flip(1)], 0).cuda()).cpu()
     assert torch.equal(rec2[0], rec[0])

@@ -138,3 +138,109 @@ def test_frechet_distance_matches_reference_function():
         np.testing.assert_allclose(got, float(z[f"fd{i}"]), rtol=2e-4)      # fp32 SVDs of ill-conditioned covariance products
     x = torch.from_numpy(z["a1"])
     assert abs(frechet_distance(x, x.clone()).item()) < 1e-2 * float(z["fd1"])
+
+
+def _load_state_fixture(name):
+    import os
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    after = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("after/")}
+    cfg = {k[4:]: (z[k].tolist() if z[k].ndim else z[k].item()) for k in z.files if k.startswith("cfg_")}
+    return z, sd, after, cfg
+
+
+@pytest.mark.parametrize("name", ["vqvae_init_tiled", "vqvae_init"])
+def test_vqvae_codebook_data_init_matches_reference(name):
+    """The first train-mode forward of a fresh model: Codebook._init_embeddings (videogpt_vq_vae.py:160-172) + _tile's repeat and
+    jitter (:151-158, the `_tiled` fixture has 16 latents for 24 codes) with the reference's permutations and noise injected."""
+    z, sd, after, cfg = _load_state_fixture(name)
+    noise = {k: torch.from_numpy(z[k]) for k in ("noise_init", "noise") if k in z.files}
+    with torch.no_grad():
+        out, new = vqvae.forward_train(torch.from_numpy(z["x"]), sd, cfg, z["perm"], init_perm=z["perm_init"],
+                                       init_noise=noise.get("noise_init"), noise=noise.get("noise"))
+    np.testing.assert_allclose(out["pred_data"].numpy(), z["pred"], atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["losses"]["recon_loss"].item(), z["recon_loss"], rtol=1e-5)
+    np.testing.assert_allclose(out["losses"]["commitment_loss"].item(), z["commitment_loss"], rtol=1e-5)
+    for k in ("codebook.embeddings", "codebook.N", "codebook.z_avg"):
+        np.testing.assert_allclose(new[k].numpy(), after[k].numpy(), atol=2e-6, rtol=1e-5, err_msg=k)
+    assert (new["codebook.N"] < 1).any() == (name == "vqvae_init_tiled")          # the tiled case restarts dead codes
+
+
+def test_near_tie_vectors_oracle_follows_the_reference(golden):
+    """tests/golden/neartie.npz: arg-min / Gumbel arg-max decided on margins of 1e-7 ... 1e-3.  The oracle runs the same torch-CPU
+    ops as the reference, so it must reproduce the reference's choice on EVERY vector (ties included); the fp64 evaluation shows
+    which of those choices fp32 rounding made."""
+    sd, a, cfg = golden("neartie")
+    z = torch.from_numpy(a["cb/z"])
+    idx, _ = vqvae.nearest_code(z, torch.from_numpy(a["cb/codebook"]))
+    assert np.array_equal(idx.view(-1).numpy(), a["cb/ref_idx"])
+    flips = a["cb/ref_idx"] != a["cb/winner64"]
+    assert flips.any() and np.abs(a["cb/margin64"][flips]).max() < 2e-5           # the reference itself is fp32-noisy below that
+    K = cfg["K"]
+    lc, lu = torch.from_numpy(a["gum/logits_c"]), torch.from_numpy(a["gum/logits_u"])
+    xt, t = torch.from_numpy(a["gum/xt"]), torch.from_numpy(a["gum/t"])
+    rec = d3pm.cf_mix(d3pm.predict_start_from_logits(lc)[:, :-1], d3pm.predict_start_from_logits(lu)[:, :-1], cfg["guidance"])
+    post = d3pm.q_posterior(rec, d3pm.index_to_log_onehot(xt, K + 1), t, sd)
+    tok = d3pm.gumbel_argmax(post, cfg["noise_seed"], int(a["gum/stream"]))
+    assert np.array_equal(tok.numpy(), a["gum/ref_tok"])
+    flips = a["gum/ref_tok"] != a["gum/winner64"]
+    assert np.abs(a["gum/margin64"][flips]).max() < 5e-6
+    assert (np.abs(a["gum/margin64"]) < 1e-4).sum() >= 20                          # the stress actually happens
+
+
+def test_product_schedule_and_sample_time_match_reference(golden):
+    """The PRODUCT's own schedule buffers (gsdd_amd.d3pm.DiffusionTransformer.__init__, not the oracle's) bit-equal the reference's
+    (diffusion_transformer.py:115-149), and its sample_time('importance') (:368-389) draws the reference's (t, pt) under the same
+    torch seed once every Lt_count passed 10 -- and falls back to uniform while one has not."""
+    import gsdd_amd
+    sd, a, cfg = golden("d3pm_L64")
+    d = gsdd_amd.DalleMaskImageEmbedding(num_embed=cfg["K"], spatial_size=cfg["spatial"], embed_dim=64)
+    tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=cfg["L"], block_activate="GELU2",
+                                        content_spatial_size=cfg["spatial"], condition_dim=cfg["cond_dim"], diffusion_step=cfg["T"])
+    dm = gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=cfg["T"], alpha_init_type="alpha1", guidance_scale=2,
+                                       content_seq_len=cfg["L"])
+    for name in gsdd_amd.d3pm.SCHED_ORDER:
+        assert torch.equal(getattr(dm, name), sd[name]), name
+    assert dm.Lt_history.shape == sd["Lt_history"].shape and dm.empty_text_embed.dtype == torch.float64
+    _, n, ncfg = golden("neartie")
+    dm.Lt_count.fill_(11.0)
+    dm.Lt_history.copy_(torch.from_numpy(n["st/Lt_history"]))
+    torch.manual_seed(int(n["st/seed"]))
+    t, pt = dm.sample_time(64, "cpu", "importance")
+    assert np.array_equal(t.numpy(), n["st/t"]) and np.array_equal(pt.numpy(), n["st/pt"])
+    assert len(np.unique(n["st/pt"])) > 10                                         # genuinely non-uniform
+    dm.Lt_count[3] = 10.0
+    torch.manual_seed(int(n["st/seed_uniform"]))
+    t, pt = dm.sample_time(64, "cpu", "importance")
+    assert np.array_equal(t.numpy(), n["st/t_uniform"]) and np.array_equal(pt.numpy(), n["st/pt_uniform"])
+
+
+@pytest.mark.parametrize("tag", ["zero", "cond"])
+def test_glue_oracle_matches_reference(golden, tag):
+    """discrete_diffusion.py:16-83 restated with the oracle's pieces against the reference's own output dict (glue_L64.npz)."""
+    _, a, cfg = golden("glue_L64")
+    sdv, av, cfgv = golden(str(cfg["vqvae"]))
+    sdd, ad, cfgd = golden(str(cfg["d3pm"]))
+    x = torch.from_numpy(av["x"])
+    B = x.shape[0]
+    rows = {str(t): torch.from_numpy(a["text_table"][i]) for i, t in enumerate(list(a["texts"]) + [""])}
+    emb = torch.stack([rows[str(t)] for t in a["texts"]]).unsqueeze(1)
+    cf = torch.stack([rows[""]] * B).unsqueeze(1)
+    if tag == "zero":
+        emb, cf = torch.zeros_like(emb), torch.zeros_like(cf)
+    t = torch.from_numpy(a["t"])
+    with torch.no_grad():
+        quant = vqvae.encode(x, sdv, cfgv)
+        loss, _, pred, _ = d3pm.train_loss(quant.view(B, -1), emb, t, torch.ones(B) / cfgd["T"], sdd, cfg["noise_seed"], int(cfg["stream"]))
+        tok = d3pm.sample(B, cfgd["L"], emb, cf, sdd, cfgd["guidance"], cfg["noise_seed"], stream0=int(cfg["stream"]) + 1)
+        single = vqvae.decode(pred.view(quant.shape), sdv, cfgv)
+        clips = vqvae.decode(tok.view(quant.shape), sdv, cfgv)
+        test = vqvae.decode(quant, sdv, cfgv)
+    np.testing.assert_allclose(loss.item(), a[f"{tag}/losses"], rtol=1e-5)
+    assert np.array_equal(tok.numpy(), a[f"{tag}/content_token"])
+    np.testing.assert_allclose(single.numpy(), a[f"{tag}/pred_single_step"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(clips.numpy(), a[f"{tag}/pred_data"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(test.numpy(), a[f"{tag}/test"], atol=2e-5, rtol=1e-5)
+
+

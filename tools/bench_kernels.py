@@ -31,9 +31,15 @@ def main():
         q = torch.randn((3 * H, M, 4), device=dev)
         out = torch.empty((M, H * 4), device=dev)
         aws = ops.d3pm_attention_workspace(B2, L, H, dev)
-        ms = timeit(lambda: ops.d3pm_attention(q[0:H], q[H:2 * H], q[2 * H:], B2, L, H, out, ws=aws))
         fl = 16.0 * L * L * H * B2
-        print(f"attention  B2={B2} L={L}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
+        for scale in (1.0, 3.0):                 # 1: near-uniform softmax; 3: peaky rows
+            qs = q * scale
+            ops.d3pm_attention(qs[0:H], qs[H:2 * H], qs[2 * H:], B2, L, H, out, ws=aws)      # pre-split images made once
+            for pbits in ("22", "11"):
+                os.environ["GSDD_ATTN_P"] = pbits
+                ms = timeit(lambda: ops.d3pm_attention(qs[0:H], None, None, B2, L, H, out, ws=aws))
+                print(f"attention  B2={B2} L={L} q,k x{scale:g} P{pbits}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
+        os.environ.pop("GSDD_ATTN_P", None)
     if "gemm" in which:
         x = torch.randn((M, D), device=dev)
         stats = torch.empty((M, 2), device=dev)
