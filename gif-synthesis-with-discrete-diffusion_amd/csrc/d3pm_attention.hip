@@ -330,6 +330,38 @@ __device__ __forceinline__ void round_p8(const float (&p)[8], uint4& hi) {
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
 }
 
+// lo = f16(p - hi) for an hi made by round_p8 (the second half of split_p8)
+__device__ __forceinline__ void resid_p8(const float (&p)[8], const uint4& hi, uint4& lo) {
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "v_fma_mix_f32 %4, %20, -1.0, %12 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %20, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %6, %21, -1.0, %14 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %7, %21, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %8, %22, -1.0, %16 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %22, -1.0, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %23, -1.0, %18 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %23, -1.0, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_cvt_pk_f16_f32 %2, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %3, %10, %11\n\t"
+        "s_nop 1"
+        : "=&v"(lo.x), "=&v"(lo.y), "=&v"(lo.z), "=&v"(lo.w),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
+          "v"(hi.x), "v"(hi.y), "v"(hi.z), "v"(hi.w));
+}
+// true if any of the 8 non-negative f16 in hi exceeds the f16 replicated in both halves of thr2 (positive f16 order like their bit
+// patterns: packed u16 max): 3 v_pk_max_u16 to fold the eight, one more against the threshold, one v_cmp
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool any_gt_h8(const uint4& hi, uint32_t thr2) {
+    const us2 a = __builtin_bit_cast(us2, hi.x), b = __builtin_bit_cast(us2, hi.y), c = __builtin_bit_cast(us2, hi.z),
+              d = __builtin_bit_cast(us2, hi.w), t = __builtin_bit_cast(us2, thr2);
+    const us2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(m, t)) != thr2;
+}
+
 // Pre-split K and V once per (b,h) into the exact LDS images the attention workgroups consume (16 query blocks
 // share them), so staging inside the attention kernel is a plain copy:
 //   Kp[row][2] uint4 : pieces A=[k1|k2], B=[k3|k1] (bf16), slots swapped for (key&15)>=8
@@ -346,14 +378,60 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
     kv_image_store_v(vs, row, vp);
 }
 
+// One pass over the pair-tiles of a staged chunk for the wave's 4 x 16 queries.  MODE 1: P = hi + lo; 0: hi only; 2: hi, and lo only
+// where a tile holds a probability above the lane's threshold thr2 (see the kernel's note) -- returns the number of (pair-tile,
+// query sub-tile) pairs that skipped the lo half.
+template <int KC4, int MODE>
+__device__ __forceinline__ int attn_tiles(const AttnSmem4<KC4>& sm, int buf, int npairs, const uint4* kb, int kstep, int lg, int li,
+                                          const uint4 (&qfrag)[4], f32x4 (&acc)[4], const uint32_t (&thr2)[4]) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int skipped = 0;
+    for (int u = 0; u < npairs; ++u) {
+        const bf16x8 kf0 = as_frag(kb[(2 * u) * kstep]);
+        const bf16x8 kf1 = as_frag(kb[(2 * u + 1) * kstep]);
+        const f16x8 vb = as_h8(sm.v[buf][u][lg][li]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, as_frag(qfrag[j]), zero, 0, 0, 0);
+            const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, as_frag(qfrag[j]), zero, 0, 0, 0);
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(s0[r]); p[4 + r] = __builtin_amdgcn_exp2f(s1[r]); }
+            uint4 hi, lo;
+            if (MODE == 1) {
+                split_p8(p, hi, lo);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
+            } else {
+                round_p8(p, hi);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
+                if (MODE == 2) {
+                    if (__any(any_gt_h8(hi, thr2[j]))) {             // wave-uniform: some probability of this tile matters
+                        resid_p8(p, hi, lo);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
+                    } else {
+                        ++skipped;
+                    }
+                }
+            }
+        }
+    }
+    return skipped;
+}
+
 // Diagnostic: how often the rare "accumulator overflowed, redo this chunk with a larger exponent offset" branch ran (one count per
 // workgroup and redo attempt).  The kernel's cost depends on the data through that branch only; bench.py reports the count per pass.
 __device__ unsigned long long g_attn_redo_events = 0ull;
 
-// LO = true: P = hi + lo (22 bits, the parity default).  LO = false: P = hi (11 bits): 12 of the 16 split instructions and one
-// of the two P.V MFMAs per 512 scores go away; the error this costs is measured in tests/test_gpu_attention_variants.py and
-// tabled in DESIGN.md -- selected only by GSDD_ATTN_P=11.
-template <int KC4, bool LO = true>
+// PM selects how the probabilities reach the P.V product:
+//   PM = 1   P = hi + lo (22 bits) everywhere: the parity default.
+//   PM = 0   P = hi (11 bits): 12 of the 16 split instructions and one of the two P.V MFMAs per 512 scores go away (GSDD_ATTN_P=11).
+//   PM >= 2  adaptive: the lo half is only added for a (16-query, 32-key) tile in which some probability exceeds 2^-PM of that
+//            query's row sum so far.  A probability below that carries a rounding error below 2^-(12+PM) of the row sum; the
+//            errors of the skipped tiles add up (randomly signed) to at most 2^-(PM/2) * 2^-12 / sqrt(3) of |v - o|.  With flat
+//            rows everything after the first few hundred keys is "small"; with peaky rows only the tiles holding a peak pay.
+// The error each mode costs is measured by tools/attn_error.py and tabled in DESIGN.md.
+template <int KC4, int PM = 1>
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
                                                                 const uint4* __restrict__ vp, int B, int L, int H,
                                                                 float* __restrict__ out, float* __restrict__ lse) {
@@ -445,6 +523,13 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         }
     }
 
+    bool prescan = false;                       // wave-uniform
+    // PM >= 2: whether this wave tests tiles at all is decided chunk by chunk.  The first chunk has no row sum to compare with; after
+    // that a chunk runs the adaptive loop, and if fewer than half of its tiles could skip the lo half the wave goes back to the plain
+    // hi + lo loop (no per-tile test, one basic block per pair-tile) and probes again later, each time twice as much later (a row
+    // that was not flat after 384 keys seldom becomes flat): chunks 1, 6, 15, 32, ...
+    bool adapt = false;
+    int probe = 1, backoff = 4;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(c + 1);
@@ -452,39 +537,57 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         const uint4* kb = kbase0 + buf * kbuf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) sav[j] = acc[j];
-        for (int attempt = 0; attempt < 16; ++attempt) {
-            for (int u = 0; u < npairs; ++u) {
-                const bf16x8 kf0 = as_frag(kb[(2 * u) * kstep]);
-                const bf16x8 kf1 = as_frag(kb[(2 * u + 1) * kstep]);
-                const f16x8 vb = as_h8(sm.v[buf][u][lg][li]);
+        // attempt -1 = "pre-scan": when the previous chunk of this wave had to move an exponent offset, the scores of this chunk are
+        // scanned for their maximum BEFORE it is processed and the offsets are moved ahead of the overflow (an S-only pass, ~1/4 of a
+        // chunk) instead of after it (the pass plus the whole chunk again).  Rows whose maximum keeps growing along the sequence
+        // (peaky softmax rows) then cost ~1.3x a flat row instead of ~2.5x; flat rows never pre-scan.
+        bool moved = false;
+        for (int attempt = prescan ? -1 : 0; attempt < 16; ++attempt) {
+          if (attempt >= 0) {
+            uint32_t thr2[4] = {0u, 0u, 0u, 0u};
+            if (PM >= 2 && adapt) {
+                // threshold of query li = 2^-PM * its row sum at the start of this chunk (accumulator column 12, row li: lane
+                // 16 (li >> 2) + 12, register li & 3), as an f16 replicated in both halves.  A zero row sum (first chunk) makes every
+                // tile take the lo half; an inf threshold (row sum beyond the f16 range) none -- both are what the bound wants.
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, as_frag(qfrag[j]), zero, 0, 0, 0);
-                    const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, as_frag(qfrag[j]), zero, 0, 0, 0);
-                    float p[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(s0[r]); p[4 + r] = __builtin_amdgcn_exp2f(s1[r]); }
-                    uint4 hi, lo;
-                    if (LO) {
-                        split_p8(p, hi, lo);
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
-                    } else {
-                        round_p8(p, hi);
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
-                    }
+                    const int src = ((li >> 2) << 4) + 12;
+                    const float r0 = __shfl(sav[j][0], src), r1 = __shfl(sav[j][1], src), r2 = __shfl(sav[j][2], src),
+                                r3 = __shfl(sav[j][3], src);
+                    const int rr = li & 3;
+                    const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
+                    const _Float16 th = (_Float16)(rs * (1.0f / (float)(1 << PM)));
+                    const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, th);
+                    thr2[j] = hb | (hb << 16);
                 }
             }
+            int skipped = 0;
+            if (PM == 0) attn_tiles<KC4, 0>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2);
+            else if (PM == 1 || !adapt) attn_tiles<KC4, 1>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2);
+            else skipped = attn_tiles<KC4, 2>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2);
             // overflow screen (f16 hi part saturated to inf somewhere in this chunk): rare
             // (inf and NaN survive additions, and full-rate adds are cheaper than sixteen half-rate compares)
             float chk = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) chk += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
             const bool bad = !(fabsf(chk) < 3.0e38f);
-            if (!__any(bad)) break;
+            if (!__any(bad)) {
+                if (PM >= 2) {
+                    if (adapt) {
+                        if (2 * skipped < 4 * npairs) { adapt = false; probe = backoff; backoff *= 2; }
+                    } else if (--probe <= 0) {
+                        adapt = true;
+                    }
+                }
+                break;
+            }
+            moved = true;
             if (lane == 0) atomicAdd(&g_attn_redo_events, 1ull);
-            // rare path: exact maximum of this chunk's scores per query (relative to the current m), then move m so that
-            // the chunk maximum lands in (2^2, 2^3]; accumulators restart from the chunk-start copy scaled by 2^-delta.
+          }
+            // exact maximum of this chunk's scores per query (relative to the current m), then move m so that the chunk maximum lands
+            // in (2^2, 2^3]; accumulators restart from the chunk-start copy scaled by 2^-delta.  After an overflow only the queries
+            // that can overflow move (maximum >= 2^15); the pre-scan moves earlier (>= 2^12) to keep headroom for the next chunks.
+            const float trigger = attempt < 0 ? 12.f : 15.f;
             float cmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             for (int t = 0; t < 2 * npairs; ++t) {
                 const bf16x8 kf = as_frag(kb[t * kstep]);
@@ -498,7 +601,8 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
             for (int j = 0; j < 4; ++j) {
                 float cm = fmaxf(cmax[j], __shfl_xor(cmax[j], 16));        // lane (query li): max over the 4 key groups
                 cm = fmaxf(cm, __shfl_xor(cm, 32));
-                const float delta = cm >= 15.f ? ceilf(cm) - 3.f : 0.f;      // integer; only queries that can overflow
+                const float delta = cm >= trigger ? ceilf(cm) - 3.f : 0.f;   // integer
+                if (attempt < 0 && __any(delta != 0.f)) moved = true;
                 mq[j] += delta;
                 if (lg == 3) qfrag[j] = negm_frag(mq[j]);
                 // accumulator rows of this lane are queries 4*lg + r: fetch their delta from the lane holding that query
@@ -510,6 +614,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
                 sav[j] = acc[j];
             }
         }
+        prescan = moved;
         if (c + 1 < nchunks) store_chunk(buf ^ 1, c + 1);
         __syncthreads();
     }
@@ -568,11 +673,14 @@ __global__ void d3pm_cross_attention_kernel(const float* q, const float* kc, con
 
 using namespace gsdd;
 
-// A/B switch of the sampler's attention arithmetic: GSDD_ATTN_P=11 -> P carried as one f16 (hi only); default 22 (hi + lo).
-// Read on every call (cheap) so that one process can measure both.
-static int attn_p_bits() {
+// The sampler's attention arithmetic (the kernel's PM parameter).  Default: adaptive, threshold 2^-8 of the row sum ("a8").
+// GSDD_ATTN_P=22 -> 1 (hi + lo everywhere: the most exact variant), 11 -> 0 (hi only), a8 / a12 -> adaptive with threshold
+// 2^-8 / 2^-12.  Read on every call (cheap) so that one process can measure all of them.  Errors and times of each: DESIGN.md.
+static int attn_p_mode() {
     const char* e = getenv("GSDD_ATTN_P");
-    return (e != nullptr && atoi(e) == 11) ? 11 : 22;
+    if (e == nullptr) return 8;
+    if (e[0] == 'a') return atoi(e + 1) == 12 ? 12 : 8;
+    return atoi(e) == 11 ? 0 : 1;
 }
 
 extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
@@ -604,9 +712,11 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
             GSDD_CHECK_LAUNCH();
         }
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
-        const int pbits = attn_p_bits();
+        const int pmode = attn_p_mode();
         if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
-        else if (pbits == 11) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, false>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
         else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
     } else {
         hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);

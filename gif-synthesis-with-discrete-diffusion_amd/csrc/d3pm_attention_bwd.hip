@@ -12,6 +12,8 @@
 // All operand images are pre-split once per call by attn_bwd_prep_kernel (256 B per (row, head)).
 //
 // Reference semantics: autograd of FullAttention.forward (transformer_utils.py:46-62).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace gsdd {
@@ -417,12 +419,241 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
     }
 }
 
+
+// ------------------------------------------------------------------ fused backward: one pass, a wave owns 64 keys
+// The two kernels above each recompute the scores, the exponentials and dS.  This one computes them once, with the KEY on the
+// lane (as the dK/dV kernel does), and gets dQ out of the same dS:
+//   * dS (bf16 hi / lo, 8 bytes per lane and 16-query tile) crosses a wave-private LDS image [32 keys][16 queries] once and is read
+//     back transposed with ds_read_b64_tr_b16: 4 keys x 16 queries per 16-lane group arrive query-major, which is exactly the A
+//     fragment of   dQ[query][col] += dS^T[query][key] . [k1 | k2 | k3][key][col]   (one v_mfma_f32_16x16x32_bf16 per 32 keys);
+//   * a wave sums dQ over its 64 keys in the accumulator, the workgroup's four waves add their tiles into an LDS accumulator
+//     (ds_add_f32), and after each 128-query chunk the workgroup's partial sum (256 keys) is written out with plain stores to
+//     partial[key block][head][row][4]; attn_bwd_dq_reduce_kernel adds the L/256 partials (fixed order: bitwise reproducible,
+//     unlike float atomics, and ~4x cheaper per byte -- MI355X_MICROARCH.md "Global float atomics").
+// Per 512 scores: 4 score MFMAs, 8 v_exp, 2 hi/lo splits, 6 accumulate MFMAs (dV, dK, dQ) -- against 8 + 16 + 3 + 6 for the pair.
+constexpr int FQC = 128;           // queries per LDS chunk
+
+struct FusedSmem {
+    uint4 q[FQC][3];
+    uint4 g[FQC][3];
+    uint4 qv[FQC / 32][4][16];
+    uint4 gv[FQC / 32][4][16];
+    uint2 t[4][2][2][32][4];       // [wave][hi/lo][query tile][key row of the pair][8-byte chunk, XOR-swizzled by (row >> 2) & 3]
+    float dq[4][FQC][12];          // [wave][query][K-image column k1 | k2 | k3]: each wave's own sum over its 64 keys
+};
+
+// ds_read_b64_tr_b16 through the compiler's builtin: it then places the s_waitcnt itself and orders the read after the wave's own
+// LDS stores to the image (a hand-written asm read would need a manual wait, and the register moves that build the 128-bit
+// fragment from two 64-bit reads could be scheduled in front of that wait)
+typedef short bw_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const uint2* p) {
+    const bw_v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bw_v4s*)(p));
+    return __builtin_bit_cast(uint2, r);
+}
+
+template <int DBG>   // 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing experiments only)
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __restrict__ k, const float* __restrict__ v, BwdImages im,
+                                                                int B, int L, int H, float* __restrict__ dqkv,
+                                                                float* __restrict__ dq_part) {
+    extern __shared__ __attribute__((aligned(16))) char fused_raw[];
+    FusedSmem& sm = *reinterpret_cast<FusedSmem*>(fused_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkb = (L + 255) / 256;
+    const unsigned wg = bw_xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = wg % nkb;
+    const int h = (wg / nkb) % H, b = wg / (nkb * H);
+    const int64_t M = (int64_t)B * L;
+    const int64_t hrow0 = (int64_t)h * M + (int64_t)b * L;
+    const int li = lane & 15, lg = lane >> 4;
+    const int k0 = kblk * 256 + wave * 64;
+
+    uint4 kfrag[4], vfrag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ki = k0 + 16 * j + li;
+        ki = ki < L ? ki : L - 1;
+        const float4 kk = *reinterpret_cast<const float4*>(k + (hrow0 + ki) * 4);
+        const float4 vv = *reinterpret_cast<const float4*>(v + (hrow0 + ki) * 4);
+        const float ks[4] = {kk.x, kk.y, kk.z, kk.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
+        kfrag[j] = bw_col_frag(ks, lg, bw_ones_frag());
+        vfrag[j] = bw_col_frag(vs, lg, bw_ones_frag());
+    }
+    // accumulate image of this wave's keys (B operand of the dQ product), one 32-key pair-tile per jp; a pair-tile past the end of
+    // the sequence (L % 256 != 0; L % 32 == 0) is skipped as a whole below
+    uint4 kvb[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        const int kp0 = min(k0 + 32 * jp, L - 32);
+        kvb[jp] = im.kv[((hrow0 + kp0) >> 5) * 64 + lg * 16 + li];
+    }
+    const bool pair_ok[2] = {k0 < L, k0 + 32 < L};
+
+    const int nchunks = (L + FQC - 1) / FQC;
+    uint4 rq0, rq1, rg0, rg1, rqv, rgv;
+    auto load_chunk = [&](int ch) {
+        const int rows = min(FQC, L - ch * FQC);                      // multiple of 32
+        const uint4* qs = im.qp + (hrow0 + (int64_t)ch * FQC) * 3;
+        const uint4* gs = im.gp + (hrow0 + (int64_t)ch * FQC) * 3;
+        const uint4* qvs = im.qv + ((hrow0 + (int64_t)ch * FQC) >> 5) * 64;
+        const uint4* gvs = im.gv + ((hrow0 + (int64_t)ch * FQC) >> 5) * 64;
+        const int l3 = rows * 3 - 1, l2 = rows * 2 - 1;               // unconditional, clamped loads (see the dQ kernel)
+        rq0 = qs[min(tid, l3)]; rq1 = qs[min(tid + 256, l3)];
+        rg0 = gs[min(tid, l3)]; rg1 = gs[min(tid + 256, l3)];
+        rqv = qvs[min(tid, l2)]; rgv = gvs[min(tid, l2)];
+    };
+    auto store_chunk = [&]() {
+        uint4* qd = &sm.q[0][0];
+        uint4* gd = &sm.g[0][0];
+        qd[tid] = rq0; gd[tid] = rg0;
+        if (tid < FQC * 3 - 256) { qd[tid + 256] = rq1; gd[tid + 256] = rg1; }
+        (&sm.qv[0][0][0])[tid] = rqv;
+        (&sm.gv[0][0][0])[tid] = rgv;
+    };
+    // partial dQ of chunk `ch` (this workgroup's 256 keys = the four waves' slabs, three pieces of K each) -> dq_part[kblk][h][row][4]
+    auto flush_dq = [&](int ch) {
+        const int qi = ch * FQC + tid;
+        if (tid < FQC && qi < L) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* a = &sm.dq[w][tid][0];
+                const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4),
+                             a2 = *reinterpret_cast<const float4*>(a + 8);
+                s.x += (a0.x + a1.x) + a2.x; s.y += (a0.y + a1.y) + a2.y; s.z += (a0.z + a1.z) + a2.z; s.w += (a0.w + a1.w) + a2.w;
+            }
+            *reinterpret_cast<float4*>(dq_part + (((int64_t)kblk * H + h) * M + (int64_t)b * L + qi) * 4) =
+                make_float4(0.5f * s.x, 0.5f * s.y, 0.5f * s.z, 0.5f * s.w);
+        }
+    };
+
+    f32x4 acck[4], accv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acck[j][e] = 0.f; accv[j][e] = 0.f; }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    const int piece = lg < 2 ? 0 : lg - 1;                            // lane group -> piece of the query row: A A B C
+    // transpose image addresses of this lane: write = row (16 jj + li), chunk lg ^ (li >> 2);
+    // transposed read = row (4 lg + (li >> 2)) [+ 16 for the second key tile], chunk (li & 3) ^ lg
+    uint2* const tw = &sm.t[wave][0][0][li][lg ^ (li >> 2)];
+    const uint2* const tr0 = &sm.t[wave][0][0][4 * lg + (li >> 2)][(li & 3) ^ lg];
+    constexpr int T_TILE = 32 * 4, T_HL = 2 * T_TILE, T_ROW16 = 16 * 4;       // in uint2 (8-byte) units
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                                              // the previous chunk is computed: its slabs are complete, staging is free
+        if (ch > 0) flush_dq(ch - 1);
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        const int npairs = min(FQC, L - ch * FQC) >> 5;
+        for (int u = 0; u < npairs; ++u) {
+            const bf16x8 qa0 = bw_frag(sm.q[32 * u + li][piece]), qa1 = bw_frag(sm.q[32 * u + 16 + li][piece]);
+            const bf16x8 ga0 = bw_frag(sm.g[32 * u + li][piece]), ga1 = bw_frag(sm.g[32 * u + 16 + li][piece]);
+            const bf16x8 qvb = bw_frag(sm.qv[u][lg][li]), gvb = bw_frag(sm.gv[u][lg][li]);
+            f32x4 dq0 = zero, dq1 = zero;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * jp + jj;
+                    const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, bw_frag(kfrag[j]), zero, 0, 0, 0);
+                    const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, bw_frag(kfrag[j]), zero, 0, 0, 0);
+                    const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga0, bw_frag(vfrag[j]), zero, 0, 0, 0);
+                    const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga1, bw_frag(vfrag[j]), zero, 0, 0, 0);
+                    float p[8], ds[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p[e] = __builtin_amdgcn_exp2f(s0[e]); p[4 + e] = __builtin_amdgcn_exp2f(s1[e]);
+                        ds[e] = p[e] * d0[e]; ds[4 + e] = p[4 + e] * d1[e];
+                    }
+                    uint4 phi, plo, dhi, dlo;
+                    bw_split8(p, phi, plo);
+                    bw_split8(ds, dhi, dlo);
+                    accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(phi), gvb, accv[j], 0, 0, 0);
+                    accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(plo), gvb, accv[j], 0, 0, 0);
+                    acck[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(dhi), qvb, acck[j], 0, 0, 0);
+                    acck[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(dlo), qvb, acck[j], 0, 0, 0);
+                    // dS of key li (tile jj of the pair), queries 4 lg .. 4 lg + 3 of query tile 0 / 1, hi and lo
+                    uint2* w = tw + jj * (16 * 4);
+                    w[0] = make_uint2(dhi.x, dhi.y);
+                    w[T_TILE] = make_uint2(dhi.z, dhi.w);
+                    w[T_HL] = make_uint2(dlo.x, dlo.y);
+                    w[T_HL + T_TILE] = make_uint2(dlo.z, dlo.w);
+                }
+                if (DBG < 2 && pair_ok[jp]) {                         // wave-uniform
+                    // A fragments of dQ += dS^T K: keys 4 lg .. 4 lg + 3 of both tiles of the pair, query li
+                    const uint2 h0a = lds_read_tr16(tr0), h0b = lds_read_tr16(tr0 + T_ROW16);
+                    const uint2 h1a = lds_read_tr16(tr0 + T_TILE), h1b = lds_read_tr16(tr0 + T_TILE + T_ROW16);
+                    const uint2 l0a = lds_read_tr16(tr0 + T_HL), l0b = lds_read_tr16(tr0 + T_HL + T_ROW16);
+                    const uint2 l1a = lds_read_tr16(tr0 + T_HL + T_TILE), l1b = lds_read_tr16(tr0 + T_HL + T_TILE + T_ROW16);
+                    const bf16x8 kb = bw_frag(kvb[jp]);
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(h0a.x, h0a.y, h0b.x, h0b.y)), kb, dq0, 0, 0, 0);
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l0a.x, l0a.y, l0b.x, l0b.y)), kb, dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(h1a.x, h1a.y, h1b.x, h1b.y)), kb, dq1, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l1a.x, l1a.y, l1b.x, l1b.y)), kb, dq1, 0, 0, 0);
+                }
+            }
+            // the wave's 64 keys are summed: the two 16-query tiles go to the wave's own slab (columns li < 12), plain stores; the
+            // four slabs are added when the chunk is flushed (LDS float atomics into one shared tile cost ~100 cycles each here)
+            if (DBG >= 1) {
+                if (dq0[0] + dq1[0] == 123.456f) sm.dq[wave][0][0] = 1.f;       // keep the products alive
+            } else if (li < 12) {
+                float* a = &sm.dq[wave][32 * u + 4 * lg][li];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[r * 12] = dq0[r];
+                    a[(16 + r) * 12] = dq1[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    flush_dq(nchunks - 1);
+
+    // dK, dV of this wave's keys (as in the dK/dV kernel)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rowbase = lane & 48;
+            const float ak = acck[j][e], av = accv[j][e];
+            const float ak1 = __shfl(ak, rowbase + (li & 3) + 4), ak2 = __shfl(ak, rowbase + (li & 3) + 8);
+            const float av1 = __shfl(av, rowbase + (li & 3) + 4), av2 = __shfl(av, rowbase + (li & 3) + 8);
+            const int ki = k0 + 16 * j + 4 * lg + e;
+            if (li < 4 && ki < L) {
+                float* dst = dqkv + ((int64_t)b * L + ki) * (3 * H * 4);
+                dst[H * 4 + h * 4 + li] = 0.5f * ((ak + ak1) + ak2);
+                dst[2 * H * 4 + h * 4 + li] = (av + av1) + av2;
+            }
+        }
+    }
+}
+
+// dq[m][h*4 + d] = sum over key blocks of dq_part[kblk][h][m][d]   (one thread per (m, h), fixed summation order)
+__global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __restrict__ part, int nkb, int H, int64_t M,
+                                                                 float* __restrict__ dqkv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // h * M + m
+    if (i >= (int64_t)H * M) return;
+    const int h = (int)(i / M);
+    const int64_t m = i - (int64_t)h * M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kb = 0; kb < nkb; ++kb) {
+        const float4 p = *reinterpret_cast<const float4*>(part + (((int64_t)kb * H + h) * M + m) * 4);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    *reinterpret_cast<float4*>(dqkv + m * (3 * H * 4) + h * 4) = s;
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
 
 extern "C" int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H) {
-    return (int64_t)B * L * H * 16 * 16;          // 16 uint4 per (row, head): kp 2, vk 2, kv 2, qp 3, gp 3, qv 2, gv 2
+    // 16 uint4 per (row, head): kp 2, vk 2, kv 2, qp 3, gp 3, qv 2, gv 2; then the fused kernel's partial dQ: one float4 per
+    // (256-key block, row, head)
+    return (int64_t)B * L * H * 16 * 16 + (int64_t)((L + 255) / 256) * B * L * H * 16;
 }
 
 // Matrix-pipe backward; returns GSDD_OK with *done = 0 when the shape needs the VALU kernels (L % 32 != 0 or no workspace).
@@ -446,6 +677,31 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, q, k, v, o, dO, lse, M, H, im);
     GSDD_CHECK_LAUNCH();
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
+    const bool split_kernels = getenv("GSDD_ATTN_BWD_SPLIT") != nullptr;            // A/B switch (read per call): dQ kernel + dK/dV kernel
+    if (!split_kernels) {
+        float* dq_part = reinterpret_cast<float*>(reinterpret_cast<uint4*>(workspace) + rows * 16);
+        static bool fattr_done = false;
+        if (!fattr_done) {
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem)));
+            fattr_done = true;
+        }
+        const char* dbg = getenv("GSDD_FUSED_DBG");
+        const int dbgv = dbg ? atoi(dbg) : 0;
+        if (dbgv == 1) hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, grid, dim3(256), sizeof(FusedSmem), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (dbgv == 2) hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, grid, dim3(256), sizeof(FusedSmem), st, k, v, im, B, L, H, dqkv, dq_part);
+        else hipLaunchKernelGGL(attn_bwd_fused_kernel<0>, grid, dim3(256), sizeof(FusedSmem), st, k, v, im, B, L, H, dqkv, dq_part);
+        GSDD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, dq_part, (L + 255) / 256, H,
+                           M, dqkv);
+        GSDD_CHECK_LAUNCH();
+        *done = 1;
+        return GSDD_OK;
+    }
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, q, o, dO, lse, im, B, L, H, dqkv);
     GSDD_CHECK_LAUNCH();
     static bool attr_done = false;

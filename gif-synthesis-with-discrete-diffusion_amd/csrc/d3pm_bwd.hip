@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dh, const floa
 // ------------------------------------------------------------------ weight gradient: dW[n][k] += sum_m dY[m][n] * X[m][k]
 // grid (row slabs, N/64, K/64); each workgroup accumulates `slabs` x 128 rows in registers, then one atomic pass.
 constexpr int WG_ROWS = 128;
+// db != NULL: the blocks of the first K tile also add the column sums of their dY rows (the bias gradient) -- every block stages
+// those rows anyway; one atomic per column and block instead of a separate pass over dY.
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, const float* X, int ldx, int64_t M, int N, int K,
-                                                    float* dW, int slabs) {
+                                                    float* dW, int slabs, float* db) {
     __shared__ float sy[WG_ROWS][64], sx[WG_ROWS][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -132,6 +134,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool do_bias = db != nullptr && blockIdx.z == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);              // column sums of this thread's 4 columns ((tid & 15) * 4) over its rows
     for (int sl = 0; sl < slabs; ++sl) {
         const int64_t r0 = ((int64_t)blockIdx.x * slabs + sl) * WG_ROWS;
         if (r0 >= M) break;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
             }
             *reinterpret_cast<float4*>(&sy[r][c]) = vy;
             *reinterpret_cast<float4*>(&sx[r][c]) = vx;
+            cs.x += vy.x; cs.y += vy.y; cs.z += vy.z; cs.w += vy.w;
         }
         __syncthreads();
 #pragma unroll 8
@@ -159,6 +164,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
         const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int k = k0 + wk * 32 + li;
         if (n < N && k < K) atomicAdd(dW + (int64_t)n * K + k, acc[r]);
+    }
+    if (do_bias) {                                             // block-uniform
+        __syncthreads();
+        *reinterpret_cast<float4*>(&sy[tid >> 4][(tid & 15) * 4]) = cs;
+        __syncthreads();
+        if (tid < 64 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += sy[g][tid];
+            atomicAdd(db + n0 + tid, t);
+        }
     }
 }
 
@@ -511,14 +527,8 @@ extern "C" int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int
     GSDD_CHECK_ARG(N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0, "N, K and pitches must be multiples of 4");
     const int slabs = 8;
     const dim3 grid((unsigned)((M + (int64_t)WG_ROWS * slabs - 1) / ((int64_t)WG_ROWS * slabs)), (N + 63) / 64, (K + 63) / 64);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, dW, slabs);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, dW, slabs, db);
     GSDD_CHECK_LAUNCH();
-    if (db != nullptr) {
-        const int cpb = colsum_cpb(N), rows = (N <= 256 && M < 262144) ? 64 : 256;
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rows - 1) / rows), (N + cpb - 1) / cpb), dim3(256), 0,
-                           (hipStream_t)stream, dY, ldy, M, N, db, cpb, rows);
-        GSDD_CHECK_LAUNCH();
-    }
     return GSDD_OK;
 }
 
@@ -572,7 +582,7 @@ extern "C" int gsdd_d3pm_attention_bwd(const float* q, const float* k, const flo
                                        const float* lse, int B, int L, int H, float* dqkv, float* scratch, void* workspace,
                                        int64_t workspace_bytes, void* stream) {
     GSDD_CHECK_ARG(q && k && v && o && dO && lse && dqkv && B > 0 && L > 0 && H > 0, "bad args");
-    static const bool force_valu = getenv("GSDD_ATTN_BWD_VALU") != nullptr;     // A/B switch
+    const bool force_valu = getenv("GSDD_ATTN_BWD_VALU") != nullptr;            // A/B switch (read per call)
     if (!force_valu) {
         int done = 0;
         const int rc = gsdd_attention_bwd_mfma(q, k, v, o, dO, lse, B, L, H, dqkv, workspace, workspace_bytes, stream, &done);

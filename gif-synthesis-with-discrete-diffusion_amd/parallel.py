@@ -125,6 +125,16 @@ class GradReducer:
             self._pending = (self._ev[0], mid, self._ev[1])
         self.handles, self.tensors, self._ev = [], [], None
 
+    def stats(self):
+        """{'allreduce_span_ms', 'allreduce_exposed_ms', 'allreduce_mib', 'allreduce_buckets'} of the last exchange ({} before the
+        first one).  span = first bucket issued -> averaged gradients ready (overlaps the rest of the backward); exposed = the part
+        after the backward's last kernel, i.e. what the exchange adds to the step."""
+        if getattr(self, "_pending", None) is None:
+            return {}
+        span, exposed = self.elapsed_ms()
+        return {"allreduce_span_ms": span, "allreduce_exposed_ms": exposed, "allreduce_mib": self.last_bytes / 2 ** 20,
+                "allreduce_buckets": self.last_buckets}
+
     def elapsed_ms(self):
         """(span, exposed) of the last finished exchange in ms: first issue -> averaged gradients ready, and the part of it after the
         backward's last kernel (what the step actually waits for).  Synchronises on the closing event."""

@@ -48,11 +48,17 @@ class Trainer:
         return [ret]
 
     def _batches(self, loader):
+        """Batches are dealt round-robin to the ranks, in whole rounds: a trailing round that cannot serve every rank is dropped,
+        so all ranks take the same number of steps (every step holds collectives)."""
+        mine = None
         for i, batch in enumerate(loader):
             if self.limit_batches is not None and i >= self.limit_batches * self.world:
                 break
-            if i % self.world == self.rank:                                   # deal batches round-robin to the ranks
-                yield i // self.world, batch
+            if i % self.world == self.rank:
+                mine = batch
+            if i % self.world == self.world - 1:                              # the round is complete
+                yield i // self.world, mine
+                mine = None
 
     def _attach(self, model, datamodule):
         model.trainer = self
@@ -146,6 +152,14 @@ class Trainer:
                 outs.append(out.detach() if torch.is_tensor(out) else {k: v.detach() for k, v in out.items()})
             self._eval_loop(model, datamodule.val_dataloader(), model.validation_step, model.validation_epoch_end)
             model.training_epoch_end(outs)
+            if self.world > 1:                                                # measured cost of the gradient exchange (last step)
+                for m in model.modules():
+                    red = getattr(getattr(m, "_hip_trainer", None), "reducer", None)
+                    if red is not None:
+                        self.callback_metrics.update({f"comm/{k}": float(v) for k, v in red.stats().items()})
+                native = getattr(getattr(model, "_native", None), "reducer", None)
+                if native is not None:
+                    self.callback_metrics.update({f"comm/{k}": float(v) for k, v in native.stats().items()})
             self._on_epoch_checkpoint(model)
             if self.rank == 0:
                 print(f"epoch {self.current_epoch}: " + ", ".join(f"{k} {v:.5g}" for k, v in sorted(self.callback_metrics.items())

@@ -1,0 +1,91 @@
+"""The two training workloads at BASELINE.json's own sizes (no oracle at these sizes: size-independent properties):
+C2 = VQ-VAE step on 64 clips of 16x128x128 (256 channels, 3 residual blocks, 4096 codes), C4 = D3PM step on 16 token grids of
+16x16x16 per GPU (19 layers, K = 4096, T = 100).  Three optimiser steps on one fixed batch: the loss is finite and falls, the first
+step (same weights, same batch, same noise) reproduces bit for bit in a fresh model, peak memory stays under a stated bound.
+The gradients themselves are checked against autograd of the oracle at small sizes in test_gpu_training.py /
+test_gpu_vqvae_training.py; the kernels take the same code paths here (same tile shapes, only more tiles)."""
+import pytest
+import torch
+
+from tests.conftest import parity_report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gsdd_amd
+    assert torch.cuda.is_available()
+    gsdd_amd.lib()
+    return gsdd_amd
+
+
+def _d3pm(G):
+    torch.manual_seed(0)
+    d = G.DalleMaskImageEmbedding(num_embed=4096, spatial_size=[64, 64], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=19, n_embd=64, n_head=16, content_seq_len=4096, block_activate="GELU2",
+                                 content_spatial_size=[64, 64], condition_dim=512, diffusion_step=100)
+    return G.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", auxiliary_loss_weight=5e-4,
+                                  adaptive_auxiliary_loss=True, guidance_scale=2, content_seq_len=4096).cuda().train()
+
+
+def test_c4_d3pm_training_step_full_size(G):
+    import time
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    B, L, K = 16, 4096, 4096
+    g = torch.Generator().manual_seed(1)
+    tok = torch.randint(0, K, (B, L), generator=g).cuda()
+    cond = torch.zeros(B, 1, 512, device="cuda")
+    t = (torch.arange(B) * 6 + 3).cuda()                      # fixed timesteps 3 .. 93: the loss is comparable across steps
+    pt = torch.full((B,), 0.01, device="cuda")
+    torch.cuda.reset_peak_memory_stats()
+    first, losses, ms = [], [], []
+    for run in range(2):
+        dm = _d3pm(G)
+        trainer = D3PMTrainer(dm, lr=1e-3)
+        for i in range(3 if run == 0 else 1):
+            dm.set_noise(11, stream=0)                        # the same q_sample noise every step: a fixed (x_t, x_0) batch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = trainer.step(tok, cond, t=t, pt=pt)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            (losses if run == 0 else first).append(loss[0].item())
+        del trainer, dm
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    parity_report("c4_d3pm_train_full_size", {"losses": losses, "first_step_again": first[0], "ms_per_step": ms[1:3], "peak_gib": peak})
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[2] < losses[1] < losses[0], losses
+    assert first[0] == losses[0], "the first step is not bitwise repeatable"
+    assert peak < 12.0, peak
+
+
+def test_c2_vqvae_training_step_full_size(G):
+    import time
+    from gsdd_amd.vqvae_trainer import VQVAETrainer
+    B = 64
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 3, 16, 128, 128, generator=g).cuda()
+    torch.cuda.reset_peak_memory_stats()
+    first, losses, ms = [], [], []
+    for run in range(2):
+        torch.manual_seed(0)
+        vq = G.VQVAE(None, 128, 4096, 256, 3, [1, 8, 8], 16, 128).cuda().train()
+        perm = torch.randperm(B * 16 * 16 * 16, generator=torch.Generator().manual_seed(3))
+        vq.perm_source = lambda n: perm
+        trainer = VQVAETrainer(vq, lr=4e-4)
+        for i in range(3 if run == 0 else 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = trainer.step(x)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            total = (out["recon_loss"] + out["commitment_loss"]).item()
+            (losses if run == 0 else first).append(total)
+        del trainer, vq
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    parity_report("c2_vqvae_train_full_size", {"losses": losses, "first_step_again": first[0], "ms_per_step": ms[1:3], "peak_gib": peak})
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[2] < losses[0], losses                      # (step 1 re-initialises nothing: the codebook was seeded by step 0)
+    assert abs(first[0] - losses[0]) <= 1e-6 * abs(losses[0]), (first, losses)
+    assert peak < 60.0, peak

@@ -153,11 +153,18 @@ def test_two_rank_data_parallel_step_equals_global_batch(G, golden):
 
 
 # ----------------------------------------------------------------------------- attention backward kernels vs fp64 autograd
-@pytest.mark.parametrize("valu", [False, True])
-@pytest.mark.parametrize("B,L,scale", [(2, 64, 1.0), (1, 320, 1.5), (1, 1024, 1.0), (2, 96, 3.0)])
-def test_attention_backward_matches_fp64_autograd(G, B, L, scale, valu, monkeypatch):
-    """dq | dk | dv of softmax(q k^T / 2) v for head dim 4: the matrix-pipe kernels (operand images, L % 32 == 0) and the VALU
-    kernels (no workspace) against torch.autograd in fp64.  L = 320 covers a partial 256-row chunk, scale 3 peaky attention."""
+@pytest.mark.parametrize("mode", ["fused", "split", "valu"])
+@pytest.mark.parametrize("B,L,scale", [(2, 64, 1.0), (1, 320, 1.5), (1, 1024, 1.0), (2, 96, 3.0), (2, 544, 1.0)])
+def test_attention_backward_matches_fp64_autograd(G, B, L, scale, mode, monkeypatch):
+    """dq | dk | dv of softmax(q k^T / 2) v for head dim 4 against torch.autograd in fp64: the fused matrix-pipe kernel (one pass,
+    dS through an LDS transpose, partial dQ per 256-key block + reduction), the two-kernel matrix-pipe variant
+    (GSDD_ATTN_BWD_SPLIT) and the VALU kernels (no workspace).  L = 320 / 544 cover partial key blocks and query chunks (544 =
+    2 key blocks + 32, 4 query chunks + 32), scale 3 peaky attention."""
+    valu = mode == "valu"
+    if mode == "split":
+        monkeypatch.setenv("GSDD_ATTN_BWD_SPLIT", "1")
+    else:
+        monkeypatch.delenv("GSDD_ATTN_BWD_SPLIT", raising=False)
     H = 16
     g = torch.Generator().manual_seed(9)
     q = (torch.randn(B, H, L, 4, generator=g) * scale).double().requires_grad_(True)

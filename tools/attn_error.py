@@ -28,11 +28,11 @@ def main():
         qh, kh, vh = hm(q), hm(k), hm(v)
         out = torch.empty((B * L, H * 4), device="cuda")
         aws = ops.d3pm_attention_workspace(B, L, H, "cuda")
-        for pbits in ("22", "11"):
+        for pbits in ("22", "11", "a8", "a12"):
             os.environ["GSDD_ATTN_P"] = pbits
             ops.d3pm_attention(qh, kh, vh, B, L, H, out, ws=aws)
             err = (out.double() - want).abs()
-            print(json.dumps({"scale": scale, "P_bits": int(pbits), "max_err": err.max().item(), "rms_err": err.pow(2).mean().sqrt().item(),
+            print(json.dumps({"scale": scale, "P_mode": pbits, "max_err": err.max().item(), "rms_err": err.pow(2).mean().sqrt().item(),
                               "neff_median": neff.median().item(), "neff_min": neff.min().item()}), flush=True)
     os.environ.pop("GSDD_ATTN_P", None)
 
