@@ -32,10 +32,10 @@ def main():
         out = torch.empty((M, H * 4), device=dev)
         aws = ops.d3pm_attention_workspace(B2, L, H, dev)
         fl = 16.0 * L * L * H * B2
-        for scale in (0.05, 1.0, 2.0, 3.0):      # 0.05: flat softmax rows (the N(0, 0.02) init); 1: trained-like; 2, 3: peaky
+        for scale in [float(v) for v in os.environ.get("GSDD_BENCH_SCALES", "0.05,1,2,3").split(",")]:      # 0.05: flat softmax rows (the N(0, 0.02) init); 1: trained-like; 2, 3: peaky
             qs = q * scale
             ops.d3pm_attention(qs[0:H], qs[H:2 * H], qs[2 * H:], B2, L, H, out, ws=aws)      # pre-split images made once
-            for pbits in ("22", "11", "a8", "a12"):
+            for pbits in os.environ.get("GSDD_BENCH_PMODES", "22,11,a8,a12").split(","):
                 os.environ["GSDD_ATTN_P"] = pbits
                 ms = timeit(lambda: ops.d3pm_attention(qs[0:H], None, None, B2, L, H, out, ws=aws))
                 print(f"attention  B2={B2} L={L} q,k x{scale:g} P{pbits}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
