@@ -755,8 +755,13 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     uint4* vp = kp + rows * 2;
     hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
     GSDD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
-                       out, lse);
+    // same arithmetic switch as the sampler (default: adaptive lo half); the log-sum-exp comes from the same row sums
+    if (attn_p_mode() == 8)
+        hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp,
+                           B, L, H, out, lse);
+    else
+        hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
+                           out, lse);
     GSDD_CHECK_LAUNCH();
     *done = 1;
     return GSDD_OK;

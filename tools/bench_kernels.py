@@ -59,6 +59,17 @@ def main():
             print(f"attention bwd B={Bt} L={L} {name}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
         for k_ in ("GSDD_FUSED_DBG", "GSDD_ATTN_BWD_SPLIT"):
             os.environ.pop(k_, None)
+    if "wgrad" in which:
+        Mt = 16 * L
+        for (n, k) in [(64, 64), (192, 64), (256, 64), (64, 256), (4096, 64)]:
+            dY = torch.randn((Mt, n), device=dev); X = torch.randn((Mt, k), device=dev)
+            dW = torch.zeros((n, k), device=dev); db = torch.zeros((n,), device=dev)
+            ms = timeit(lambda: ops.wgrad(dY, X, dW, db))
+            dW3 = torch.zeros((1, n, k), device=dev)
+            ms2 = timeit(lambda: ops.conv_wgrad(X, dY, dW3, in_dims=(1, 1, 1, Mt), out_grid=(1, 1, Mt), cin=k, cout=n))
+            fl = 2.0 * Mt * n * k
+            print(f"wgrad M={Mt} N={n} K={k}: f32 kernel {ms * 1e3:.1f} us ({fl / ms / 1e9:.1f} TFLOP/s)   conv_wgrad (bf16x3) {ms2 * 1e3:.1f} us "
+                  f"({fl / ms2 / 1e9:.1f} TFLOP/s)")
     if "gemm" in which:
         x = torch.randn((M, D), device=dev)
         stats = torch.empty((M, 2), device=dev)
