@@ -677,12 +677,15 @@ __global__ void d3pm_cross_attention_kernel(const float* q, const float* kc, con
 
 using namespace gsdd;
 
-// The sampler's attention arithmetic (the kernel's PM parameter).  Default: adaptive, threshold 2^-8 of the row sum ("a8").
+// The sampler's attention arithmetic (the kernel's PM parameter).  Default: adaptive with threshold 2^-8 of the row sum ("a8") for
+// L >= 2048, hi + lo everywhere below that: the rounding errors of the skipped lo halves average out over the keys of a row, as
+// 1.4e-4 * sqrt(L - 256) / L for flat rows -- 2.1e-6 rms at L = 4096, but 3.8e-6 at L = 1024 (measured maximum 2.5e-5, above the
+// 2e-5 this kernel is held to), and short sequences have too few chunks to gain anything.
 // GSDD_ATTN_P=22 -> 1 (hi + lo everywhere: the most exact variant), 11 -> 0 (hi only), a8 / a12 -> adaptive with threshold
-// 2^-8 / 2^-12.  Read on every call (cheap) so that one process can measure all of them.  Errors and times of each: DESIGN.md.
-static int attn_p_mode() {
+// 2^-8 / 2^-12 at any L.  Read on every call (cheap) so that one process can measure all of them.  Errors and times: DESIGN.md.
+static int attn_p_mode(int L) {
     const char* e = getenv("GSDD_ATTN_P");
-    if (e == nullptr) return 8;
+    if (e == nullptr) return L >= 2048 ? 8 : 1;
     if (e[0] == 'a') return atoi(e + 1) == 12 ? 12 : 8;
     return atoi(e) == 11 ? 0 : 1;
 }
@@ -716,7 +719,7 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
             GSDD_CHECK_LAUNCH();
         }
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
-        const int pmode = attn_p_mode();
+        const int pmode = attn_p_mode(L);
         if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
         else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
         else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
@@ -756,7 +759,7 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
     GSDD_CHECK_LAUNCH();
     // same arithmetic switch as the sampler (default: adaptive lo half); the log-sum-exp comes from the same row sums
-    if (attn_p_mode() == 8)
+    if (attn_p_mode(L) == 8)
         hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp,
                            B, L, H, out, lse);
     else

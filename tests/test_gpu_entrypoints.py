@@ -105,3 +105,23 @@ def test_eval_entry_point(tmp_path, capsys):
     metrics = main(STAGE2 + [f"paths.output_dir={tmp_path}"])
     finite(metrics, ["total/test", "l/dummy/test"])
     assert "3 batches" in capsys.readouterr().out
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this box's single GPU
+    with the gloo backend (RCCL refuses two ranks on one device) at a toy size: the N > 1 code path -- device binding, process group,
+    barrier, per-rank times gathered, rank 0's JSON line, weak scaling of `value` -- must run and parse."""
+    import json
+    import subprocess
+    import sys
+    from src.train import ROOT
+    env = dict(os.environ, GSDD_DIST_BACKEND="gloo", GSDD_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 100), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--batch", "4", "--grid", "2", "4", "4", "--codes", "64", "--layers", "2", "--diffusion-steps", "8"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["scaling"] == "weak"
+    assert len(line["ranks"]["videos_per_s_per_rank"]) == 2 and line["ranks"]["seconds_max"] >= line["ranks"]["seconds_min"] > 0
+    assert abs(line["value"] - 8 / line["ranks"]["seconds_max"]) < 0.05 * line["value"]          # (the seconds are rounded to 1e-4)

@@ -508,3 +508,45 @@ def test_denoiser_ragged_lengths_match_oracle(G, L, spatial):
     want = od.denoiser(tok, cond, t, sd)
     got = tr.cuda()(tok.cuda(), cond.cuda(), t.cuda())
     torch.testing.assert_close(got.cpu(), want, atol=LOGIT_TOL, rtol=0)
+
+
+# ----------------------------------------------------------------------------- the attention kernel's arithmetic modes
+def test_attention_arithmetic_modes(G, golden, monkeypatch):
+    """GSDD_ATTN_P: the default (adaptive lo half for L >= 2048, hi + lo everywhere below) and the most exact mode (22) meet the bars --
+    denoiser logits of the reference fixture within 1e-4, attention within 2e-5 of fp64 on flat, trained-like and peaky rows at
+    L = 1024 and L = 4096; the measured errors of every mode (incl. a8 forced at L = 1024, a12, and the hi-only mode 11, which does
+    not meet the bars and is not a default) go to the report."""
+    sd, a, cfg = golden("d3pm_L64")
+    H = 16
+    rec = {}
+    for mode in ("default", "22", "a8", "a12", "11"):
+        if mode == "default":
+            monkeypatch.delenv("GSDD_ATTN_P", raising=False)
+        else:
+            monkeypatch.setenv("GSDD_ATTN_P", mode)
+        dm = build_d3pm(G, sd, cfg)
+        logits = dm.transformer(dev(a["step_xt"]), dev(a["step_cond"]), dev(a["step_t"])).cpu()
+        rec[f"fixture_logits_err[{mode}]"] = (logits - torch.from_numpy(a["step_logits"])).abs().max().item()
+        for L in (1024, 4096):
+            g = torch.Generator().manual_seed(3)
+            errs = []
+            for scale in (0.05, 1.0, 3.0):
+                q, k = (torch.randn(1, H, L, 4, generator=g) * scale for _ in range(2))
+                v = torch.randn(1, H, L, 4, generator=g)
+                qd, kd, vd = q.double().cuda(), k.double().cuda(), v.double().cuda()
+                want = (torch.softmax(qd @ kd.transpose(-1, -2) * 0.5, dim=-1) @ vd).permute(0, 2, 1, 3).reshape(L, H * 4)
+                hm = lambda z: z.permute(1, 0, 2, 3).reshape(H, L, 4).contiguous().cuda()
+                out = torch.empty((L, H * 4), device="cuda")
+                G.ops.d3pm_attention(hm(q), hm(k), hm(v), 1, L, H, out, ws=G.ops.d3pm_attention_workspace(1, L, H, "cuda"))
+                errs.append((out.double() - want).abs().max().item())
+            rec[f"attention_err_flat_trained_peaky[{mode}, L={L}]"] = errs
+    monkeypatch.delenv("GSDD_ATTN_P", raising=False)
+    parity_report("attention_arithmetic_modes", rec)
+    for mode in ("default", "22", "a12"):
+        assert rec[f"fixture_logits_err[{mode}]"] < LOGIT_TOL, (mode, rec)
+        for L in (1024, 4096):
+            assert max(rec[f"attention_err_flat_trained_peaky[{mode}, L={L}]"]) < 2e-5, (mode, L, rec)
+    assert max(rec["attention_err_flat_trained_peaky[a8, L=4096]"]) < 2e-5, rec
+    assert rec["attention_err_flat_trained_peaky[default, L=4096]"] == rec["attention_err_flat_trained_peaky[a8, L=4096]"]
+    assert rec["attention_err_flat_trained_peaky[default, L=1024]"] == rec["attention_err_flat_trained_peaky[22, L=1024]"]
+    assert rec["fixture_logits_err[22]"] <= rec["fixture_logits_err[11]"]
