@@ -133,7 +133,7 @@ struct BwdImages {                 // all indexed by the head-major row h*M + b*
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, const float* __restrict__ o,
                                                             const float* __restrict__ dO, const float* __restrict__ lse, int64_t M,
-                                                            int H, BwdImages im) {
+                                                            int H, BwdImages im, bool score_kv) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;      // h*M + m
     if (row >= M * H) return;
     const int h = (int)(row / M);
@@ -149,10 +149,12 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
     const float ks[4] = {rk.x, rk.y, rk.z, rk.w}, vs[4] = {rv.x, rv.y, rv.z, rv.w}, gs[4] = {rg.x, rg.y, rg.z, rg.w};
     const int sw = (int)((row >> 3) & 1);
     uint4 pa, pb;
-    bw_row_pieces(ks, pa, pb);
-    im.kp[row * 2 + sw] = pa; im.kp[row * 2 + (sw ^ 1)] = pb;
-    bw_row_pieces(vs, pa, pb);
-    im.vk[row * 2 + sw] = pa; im.vk[row * 2 + (sw ^ 1)] = pb;
+    if (score_kv) {          // score-row images of K and V: only the dQ kernel of the two-kernel variant reads them
+        bw_row_pieces(ks, pa, pb);
+        im.kp[row * 2 + sw] = pa; im.kp[row * 2 + (sw ^ 1)] = pb;
+        bw_row_pieces(vs, pa, pb);
+        im.vk[row * 2 + sw] = pa; im.vk[row * 2 + (sw ^ 1)] = pb;
+    }
     bw_row_pieces(qs, pa, pb);
     im.qp[row * 3 + 0] = pa; im.qp[row * 3 + 1] = pb; im.qp[row * 3 + 2] = bw_slot_frag(-lse[row]);
     bw_row_pieces(gs, pa, pb);
@@ -676,10 +678,11 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     im.qv = w; w += rows * 2;
     im.gv = w;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, q, k, v, o, dO, lse, M, H, im);
+    const bool split_kernels = getenv("GSDD_ATTN_BWD_SPLIT") != nullptr;            // A/B switch (read per call): dQ kernel + dK/dV kernel
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, q, k, v, o, dO, lse, M, H, im,
+                       split_kernels);
     GSDD_CHECK_LAUNCH();
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
-    const bool split_kernels = getenv("GSDD_ATTN_BWD_SPLIT") != nullptr;            // A/B switch (read per call): dQ kernel + dK/dV kernel
     if (!split_kernels) {
         float* dq_part = reinterpret_cast<float*>(reinterpret_cast<uint4*>(workspace) + rows * 16);
         static bool fattr_done = false;

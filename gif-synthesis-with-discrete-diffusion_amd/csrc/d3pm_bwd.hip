@@ -73,44 +73,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dh, const float* x, const float* stats, const float* gamma,
                                                      const int64_t* sel, int gstride, int rows_per_batch, int64_t M,
                                                      const float* dx_in, float* dx_out, float* dgamma, float* dbeta,
-                                                     int gacc_stride, int acc_by_batch) {
+                                                     int gacc_stride, int acc_by_batch, int rit) {
+    // a block covers `rit` groups of 16 rows; the gamma / beta gradient contributions of its rows are summed in registers and LDS
+    // first, so that the atomics onto the (few) gradient columns are one per column and block: with one 16-row group per block the
+    // 64 K atomics per call onto 128 addresses were most of the kernel's time
     __shared__ float sg[16][64], sb[16][64];
     const int tid = threadIdx.x, lane16 = tid & 15, rloc = tid >> 4;
-    const int64_t row = (int64_t)blockIdx.x * 16 + rloc;
-    const bool ok = row < M;
-    const int64_t rc = ok ? row : 0;
-    const int b = (int)((uint32_t)rc / (uint32_t)rows_per_batch);
-    const int64_t s = sel != nullptr ? sel[b] : 0;
     const int c = lane16 * 4;
-    const float4 d = *reinterpret_cast<const float4*>(dh + rc * 64 + c);
-    const float4 xv = *reinterpret_cast<const float4*>(x + rc * 64 + c);
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + s * gstride + c);
-    const float mean = stats[2 * rc], rstd = stats[2 * rc + 1];
-    const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
-    const float dv[4] = {d.x, d.y, d.z, d.w};
-    const float g[4] = {d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w};
-    float s1 = (g[0] + g[1]) + (g[2] + g[3]);
-    float s2 = (g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3]);
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < rit; ++it) {
+        const int64_t row = ((int64_t)blockIdx.x * rit + it) * 16 + rloc;
+        const bool ok = row < M;
+        const int64_t rc = ok ? row : 0;
+        const int b = (int)((uint32_t)rc / (uint32_t)rows_per_batch);
+        const int64_t s = sel != nullptr ? sel[b] : 0;
+        const float4 d = *reinterpret_cast<const float4*>(dh + rc * 64 + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + rc * 64 + c);
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + s * gstride + c);
+        const float mean = stats[2 * rc], rstd = stats[2 * rc + 1];
+        const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const float g[4] = {d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w};
+        float s1 = (g[0] + g[1]) + (g[2] + g[3]);
+        float s2 = (g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3]);
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
-    if (ok) {
-        float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dx_in != nullptr) o4 = *reinterpret_cast<const float4*>(dx_in + rc * 64 + c);
-        o4.x += rstd * (g[0] - m1 - xh[0] * m2); o4.y += rstd * (g[1] - m1 - xh[1] * m2);
-        o4.z += rstd * (g[2] - m1 - xh[2] * m2); o4.w += rstd * (g[3] - m1 - xh[3] * m2);
-        *reinterpret_cast<float4*>(dx_out + rc * 64 + c) = o4;
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float m1 = s1 * (1.f / 64.f), m2 = s2 * (1.f / 64.f);
+        if (ok) {
+            float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dx_in != nullptr) o4 = *reinterpret_cast<const float4*>(dx_in + rc * 64 + c);
+            o4.x += rstd * (g[0] - m1 - xh[0] * m2); o4.y += rstd * (g[1] - m1 - xh[1] * m2);
+            o4.z += rstd * (g[2] - m1 - xh[2] * m2); o4.w += rstd * (g[3] - m1 - xh[3] * m2);
+            *reinterpret_cast<float4*>(dx_out + rc * 64 + c) = o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ag[e] += dv[e] * xh[e]; ab[e] += dv[e]; }
+        }
     }
     if (dgamma != nullptr) {
-        // the 16 rows of a block belong to one batch element when rows_per_batch % 16 == 0 (checked on the host)
+        // the rows of a block belong to one batch element when rows_per_batch % (16 * rit) == 0 (checked on the host)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sg[rloc][c + e] = ok ? dv[e] * xh[e] : 0.f; sb[rloc][c + e] = ok ? dv[e] : 0.f; }
+        for (int e = 0; e < 4; ++e) { sg[rloc][c + e] = ag[e]; sb[rloc][c + e] = ab[e]; }
         __syncthreads();
         if (tid < 64) {
             float a = 0.f, bb = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a += sg[r][tid]; bb += sb[r][tid]; }
-            const int64_t row0 = (int64_t)blockIdx.x * 16;
+            const int64_t row0 = (int64_t)blockIdx.x * rit * 16;
             const int b0 = (int)((uint32_t)(row0 < M ? row0 : 0) / (uint32_t)rows_per_batch);
             const int64_t slot = acc_by_batch ? b0 : 0;
             atomicAdd(dgamma + slot * gacc_stride + tid, a);
@@ -515,8 +523,10 @@ extern "C" int gsdd_ln_bwd(const float* dh, const float* x, const float* stats, 
     GSDD_CHECK_ARG(C == 64 && M > 0 && rows_per_batch > 0, "kernel is specialised for 64 features");
     GSDD_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "dgamma/dbeta come together");
     GSDD_CHECK_ARG(!acc_by_batch || rows_per_batch % 16 == 0, "per-batch accumulation needs rows_per_batch % 16 == 0");
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, (hipStream_t)stream, dh, x, stats, gamma,
-                       sel, gstride, rows_per_batch, M, dx_in, dx_out, dgamma, dbeta, gacc_stride, acc_by_batch);
+    int rit = 4;                                               // 16-row groups per block: fewer, fatter atomics
+    while (rit > 1 && ((acc_by_batch && rows_per_batch % (16 * rit) != 0) || M < (int64_t)16 * rit * 512)) rit >>= 1;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((M + 16 * rit - 1) / (16 * rit))), dim3(256), 0, (hipStream_t)stream, dh, x, stats,
+                       gamma, sel, gstride, rows_per_batch, M, dx_in, dx_out, dgamma, dbeta, gacc_stride, acc_by_batch, rit);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

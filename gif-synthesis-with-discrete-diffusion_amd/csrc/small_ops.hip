@@ -37,13 +37,19 @@ __global__ void adaln_table_kernel(const float* emb, int T, int D, const float* 
     out[i] = j < D ? 1.f + s : s;                          // (1 + scale) | shift
 }
 
-__global__ void small_linear_kernel(const float* x, int R, int Cin, const float* w, const float* b, int Cout, float* y) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * Cout) return;
+// one wave per output element: the lanes stride over Cin (coalesced rows of x and w), then a wave reduction
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, int R, int Cin, const float* w, const float* b, int Cout,
+                                                           float* y) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= R * Cout) return;                               // wave-uniform
+    const int lane = threadIdx.x & 63;
     const int r = i / Cout, j = i % Cout;
+    const float* xr = x + (int64_t)r * Cin;
+    const float* wr = w + (int64_t)j * Cin;
     float s = 0.f;
-    for (int k = 0; k < Cin; ++k) s = fmaf(x[(int64_t)r * Cin + k], w[(int64_t)j * Cin + k], s);
-    y[i] = s + (b != nullptr ? b[j] : 0.f);
+    for (int k = lane; k < Cin; k += 64) s = fmaf(xr[k], wr[k], s);
+    s = wave_sum(s);
+    if (lane == 0) y[i] = s + (b != nullptr ? b[j] : 0.f);
 }
 
 // ------------------------------------------------------------------ axial attention (model_utils.py:318-337, :586-600)
@@ -264,7 +270,7 @@ extern "C" int gsdd_small_linear(const float* x, int R, int Cin, const float* w,
                                  void* stream) {
     GSDD_CHECK_ARG(x && w && y && R > 0 && Cin > 0 && Cout > 0, "bad args");
     const int n = R * Cout;
-    hipLaunchKernelGGL(small_linear_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, R, Cin, w, b, Cout,
+    hipLaunchKernelGGL(small_linear_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, R, Cin, w, b, Cout,
                        y);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;

@@ -107,6 +107,24 @@ def test_eval_entry_point(tmp_path, capsys):
     assert "3 batches" in capsys.readouterr().out
 
 
+def test_evaluation_hooks_with_a_stand_in_encoder(tmp_path):
+    """`do_evaluation: true` (text_motion_model.py:98-101, :118-121): validation batches are sampled, pushed through the evaluator
+    (de-normalise, 224 resize on the preprocessing kernel, features) and the Frechet statistic is logged as `Metrics/fvd-val` at epoch
+    end.  The I3D encoder cannot exist offline; the stand-in pooling encoder exercises the same plumbing."""
+    metrics = run_train(tmp_path, STAGE1 + ["trainer.max_epochs=1", "model.do_evaluation=true",
+                                            "model.evaluator.videoencoder._target_=src.utils.evaluator.MeanPoolEncoder"])
+    assert "Metrics/fvd-val" in metrics and torch.isfinite(torch.tensor(metrics["Metrics/fvd-val"]))
+    from src.utils.evaluator import Evaluator, MeanPoolEncoder
+    ev = Evaluator("cuda", MeanPoolEncoder(), target_resolution=32)
+    g = torch.Generator().manual_seed(0)
+    clips = torch.randn(6, 3, 4, 16, 16, generator=g).cuda()
+    ev.push_vals({"video": clips}, 0, clips)
+    assert abs(ev.evaluate_metrics()["fvd"]) < 1e-3                     # identical sets: distance 0
+    ev.reset()
+    ev.push_vals({"video": clips}, 0, clips + 1.0)
+    assert ev.evaluate_metrics()["fvd"] > 1e-2
+
+
 def test_bench_two_ranks_rehearsal(tmp_path):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this box's single GPU
     with the gloo backend (RCCL refuses two ranks on one device) at a toy size: the N > 1 code path -- device binding, process group,

@@ -267,14 +267,18 @@ def attention_ref(q, k, v):
 
 @pytest.mark.parametrize("use_ws", [True, False])
 @pytest.mark.parametrize("B,L,spike", [(2, 64, False), (1, 1024, False), (2, 4096, False), (1, 512, True), (1, 48, False),
-                                       (2, 37, False), (1, 301, False)])          # ragged lengths take the VALU kernel
+                                       (2, 37, False), (1, 301, False),             # ragged lengths take the VALU kernel
+                                       (1, 2048, False), (1, 2080, False),          # adaptive mode with a full / partial last chunk
+                                       (1, 2304, True), (1, 4096, "grow")])         # overflow redo, then the pre-scan path, in adaptive mode
 def test_d3pm_attention(G, B, L, spike, use_ws):
     H = 16
     g = torch.Generator().manual_seed(5)
     q = torch.randn(B, H, L, 4, generator=g) * 1.5
     k = torch.randn(B, H, L, 4, generator=g) * 1.5
     v = torch.randn(B, H, L, 4, generator=g)
-    if spike:       # force the rare running-max raise: one key far above the first tile's maximum
+    if spike == "grow":   # keys that grow along the sequence: every chunk holds a new row maximum (redo once, then pre-scans)
+        k = k * torch.linspace(0.2, 6.0, L).view(1, 1, L, 1)
+    elif spike:     # force the rare running-max raise: one key far above the first tile's maximum
         k[:, :, L // 2 + 3] = q[:, :, 7] * 40.0
         k[:, :, 5] *= 0.01
     want = attention_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, H * 4)
