@@ -256,6 +256,10 @@ def main():
                     return round(B / d, 4), ops.d3pm_attention_redo_count(reset=True)
                 extra = {}
                 extra["zero_cond"], extra["redo_chunks_zero_cond"] = timed(torch.zeros_like(cond))
+                if args.lanes == 1 and B % 2 == 0 and B // 2 >= 4:
+                    dm.sample_lanes = 2                        # two half-batches on two HIP streams (same tokens: the noise key is the
+                    extra["two_lanes"], _ = timed(cond)        # global row); not the headline: per-launch timing wants one lane
+                    dm.sample_lanes = 1
                 trained_like_weights(dm)
                 extra["trained_like"], extra["redo_chunks_trained_like"] = timed(cond)
                 extra["unit"] = "videos/s"

@@ -28,7 +28,7 @@ def main():
         qh, kh, vh = hm(q), hm(k), hm(v)
         out = torch.empty((B * L, H * 4), device="cuda")
         aws = ops.d3pm_attention_workspace(B, L, H, "cuda")
-        for pbits in ("22", "11", "a8", "a12"):
+        for pbits in os.environ.get("GSDD_BENCH_PMODES", "22,11,a8,a12").split(","):
             os.environ["GSDD_ATTN_P"] = pbits
             ops.d3pm_attention(qh, kh, vh, B, L, H, out, ws=aws)
             err = (out.double() - want).abs()
