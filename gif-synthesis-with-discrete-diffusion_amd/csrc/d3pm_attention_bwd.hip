@@ -120,6 +120,23 @@ __device__ __forceinline__ void bw_split8(const float (&x)[8], uint4& hi, uint4&
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
 
+// The same split in plain C (the fused kernel): hipcc emits v_cvt_pk_bf16_f32 / v_lshlrev / v_and / v_pk_add_f32 / v_cvt_pk_bf16_f32
+// for it, pads the hazards itself, and -- unlike an asm block -- can interleave the pieces with the neighbouring matrix instructions.
+typedef __bf16 bw_bf2 __attribute__((ext_vector_type(2)));
+typedef float bw_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bw_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const bw_f2 x = {a, b};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bw_bf2));
+    const bw_f2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bw_bf2));
+}
+__device__ __forceinline__ void bw_split8c(const float (&x)[8], uint4& hi, uint4& lo) {
+    bw_split2(x[0], x[1], hi.x, lo.x);
+    bw_split2(x[2], x[3], hi.y, lo.y);
+    bw_split2(x[4], x[5], hi.z, lo.z);
+    bw_split2(x[6], x[7], hi.w, lo.w);
+}
+
 struct BwdImages {                 // all indexed by the head-major row h*M + b*L + i
     uint4* kp;                     // [rows][2]  score-row image of K (slots swapped for (row&15) >= 8, as the forward's)
     uint4* vk;                     // [rows][2]  score-row image of V
@@ -430,20 +447,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
 //   * dS (bf16 hi / lo, 8 bytes per lane and 16-query tile) crosses a wave-private LDS image [32 keys][16 queries] once and is read
 //     back transposed with ds_read_b64_tr_b16: 4 keys x 16 queries per 16-lane group arrive query-major, which is exactly the A
 //     fragment of   dQ[query][col] += dS^T[query][key] . [k1 | k2 | k3][key][col]   (one v_mfma_f32_16x16x32_bf16 per 32 keys);
-//   * a wave sums dQ over its 64 keys in the accumulator, the workgroup's four waves add their tiles into an LDS accumulator
-//     (ds_add_f32), and after each 128-query chunk the workgroup's partial sum (256 keys) is written out with plain stores to
+//   * a wave sums dQ over its 64 keys in the accumulator, adds the three K pieces across lanes (two DPP adds) and stores the 4
+//     columns to its own slab [column][query] (one ds_write_b128 per 16-query tile; LDS float atomics into one shared tile cost
+//     ~100 cycles each here); after each 128-query chunk the four slabs (256 keys) are added and written out with plain stores to
 //     partial[key block][head][row][4]; attn_bwd_dq_reduce_kernel adds the L/256 partials (fixed order: bitwise reproducible,
 //     unlike float atomics, and ~4x cheaper per byte -- MI355X_MICROARCH.md "Global float atomics").
+//   * ONE barrier per chunk: the query-side staging and the slabs are double-buffered by chunk parity, so the next chunk's staging
+//     stores and the previous chunk's slab flush run inside the compute phase instead of between two barriers (measured: the two
+//     barriers with the flush and the staging stores between them cost 15 % of the kernel).
 // Per 512 scores: 4 score MFMAs, 8 v_exp, 2 hi/lo splits, 6 accumulate MFMAs (dV, dK, dQ) -- against 8 + 16 + 3 + 6 for the pair.
 constexpr int FQC = 128;           // queries per LDS chunk
+constexpr int FSLAB = FQC + 8;     // slab column stride in floats (the 16-byte stores of lanes li = 0..3 land on distinct banks)
 
-struct FusedSmem {
+struct FusedStage {
     uint4 q[FQC][3];
     uint4 g[FQC][3];
     uint4 qv[FQC / 32][4][16];
     uint4 gv[FQC / 32][4][16];
+};
+struct FusedSmem {
+    FusedStage st[2];              // by chunk parity
     uint2 t[4][2][2][32][4];       // [wave][hi/lo][query tile][key row of the pair][8-byte chunk, XOR-swizzled by (row >> 2) & 3]
-    float dq[4][FQC][12];          // [wave][query][K-image column k1 | k2 | k3]: each wave's own sum over its 64 keys
+    float dq[2][4][4][FSLAB];      // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
 };
 
 // ds_read_b64_tr_b16 through the compiler's builtin: it then places the s_waitcnt itself and orders the read after the wave's own
@@ -453,6 +478,13 @@ typedef short bw_v4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_read_tr16(const uint2* p) {
     const bw_v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bw_v4s*)(p));
     return __builtin_bit_cast(uint2, r);
+}
+// x[lane] + x[lane + 4] + x[lane + 8] within a 16-lane row (DPP row_shl; lanes past the row read 0): the sum of the three K pieces
+__device__ __forceinline__ float bw_piece_sum(float x) {
+    const int xi = __float_as_int(x);
+    const float a = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x104, 0xf, 0xf, true));
+    const float b = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x108, 0xf, 0xf, true));
+    return (x + a) + b;
 }
 
 template <int DBG>   // 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing experiments only)
@@ -483,14 +515,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
         vfrag[j] = bw_col_frag(vs, lg, bw_ones_frag());
     }
     // accumulate image of this wave's keys (B operand of the dQ product), one 32-key pair-tile per jp; a pair-tile past the end of
-    // the sequence (L % 256 != 0; L % 32 == 0) is skipped as a whole below
+    // the sequence (L % 256 != 0; L % 32 == 0) gets a zero image: its clamped keys give finite dS, times zero they add nothing
     uint4 kvb[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         const int kp0 = min(k0 + 32 * jp, L - 32);
         kvb[jp] = im.kv[((hrow0 + kp0) >> 5) * 64 + lg * 16 + li];
+        if (k0 + 32 * jp >= L) kvb[jp] = make_uint4(0u, 0u, 0u, 0u);
     }
-    const bool pair_ok[2] = {k0 < L, k0 + 32 < L};
 
     const int nchunks = (L + FQC - 1) / FQC;
     uint4 rq0, rq1, rg0, rg1, rqv, rgv;
@@ -505,28 +537,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
         rg0 = gs[min(tid, l3)]; rg1 = gs[min(tid + 256, l3)];
         rqv = qvs[min(tid, l2)]; rgv = gvs[min(tid, l2)];
     };
-    auto store_chunk = [&]() {
-        uint4* qd = &sm.q[0][0];
-        uint4* gd = &sm.g[0][0];
+    auto store_chunk = [&](int par) {
+        FusedStage& st = sm.st[par];
+        uint4* qd = &st.q[0][0];
+        uint4* gd = &st.g[0][0];
         qd[tid] = rq0; gd[tid] = rg0;
         if (tid < FQC * 3 - 256) { qd[tid + 256] = rq1; gd[tid + 256] = rg1; }
-        (&sm.qv[0][0][0])[tid] = rqv;
-        (&sm.gv[0][0][0])[tid] = rgv;
+        (&st.qv[0][0][0])[tid] = rqv;
+        (&st.gv[0][0][0])[tid] = rgv;
     };
-    // partial dQ of chunk `ch` (this workgroup's 256 keys = the four waves' slabs, three pieces of K each) -> dq_part[kblk][h][row][4]
+    // partial dQ of chunk `ch` (this workgroup's 256 keys = the four waves' slabs) -> dq_part[kblk][h][row][4]; thread = (query, column pair)
     auto flush_dq = [&](int ch) {
-        const int qi = ch * FQC + tid;
-        if (tid < FQC && qi < L) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int q = tid >> 1, c0 = 2 * (tid & 1);
+        const int qi = ch * FQC + q;
+        if (qi < L) {
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const float* a = &sm.dq[w][tid][0];
-                const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4),
-                             a2 = *reinterpret_cast<const float4*>(a + 8);
-                s.x += (a0.x + a1.x) + a2.x; s.y += (a0.y + a1.y) + a2.y; s.z += (a0.z + a1.z) + a2.z; s.w += (a0.w + a1.w) + a2.w;
+                s0 += sm.dq[ch & 1][w][c0][q];
+                s1 += sm.dq[ch & 1][w][c0 + 1][q];
             }
-            *reinterpret_cast<float4*>(dq_part + (((int64_t)kblk * H + h) * M + (int64_t)b * L + qi) * 4) =
-                make_float4(0.5f * s.x, 0.5f * s.y, 0.5f * s.z, 0.5f * s.w);
+            *reinterpret_cast<float2*>(dq_part + (((int64_t)kblk * H + h) * M + (int64_t)b * L + qi) * 4 + c0) =
+                make_float2(0.5f * s0, 0.5f * s1);
         }
     };
 
@@ -537,7 +569,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
         for (int e = 0; e < 4; ++e) { acck[j][e] = 0.f; accv[j][e] = 0.f; }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    load_chunk(0);
     const int piece = lg < 2 ? 0 : lg - 1;                            // lane group -> piece of the query row: A A B C
     // transpose image addresses of this lane: write = row (16 jj + li), chunk lg ^ (li >> 2);
     // transposed read = row (4 lg + (li >> 2)) [+ 16 for the second key tile], chunk (li & 3) ^ lg
@@ -545,17 +576,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
     const uint2* const tr0 = &sm.t[wave][0][0][4 * lg + (li >> 2)][(li & 3) ^ lg];
     constexpr int T_TILE = 32 * 4, T_HL = 2 * T_TILE, T_ROW16 = 16 * 4;       // in uint2 (8-byte) units
 
+    load_chunk(0);
+    store_chunk(0);
+    if (nchunks > 1) load_chunk(1);
+    __syncthreads();
+
     for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();                                              // the previous chunk is computed: its slabs are complete, staging is free
+        // every wave is past the barrier that ended chunk ch - 1: the other staging buffer and the other slab set are free, the slabs
+        // of chunk ch - 1 are complete
+        if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+        if (ch + 2 < nchunks) load_chunk(ch + 2);
         if (ch > 0) flush_dq(ch - 1);
-        store_chunk();
-        __syncthreads();
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        const FusedStage& st = sm.st[ch & 1];
+        float* const slab = &sm.dq[ch & 1][wave][li & 3][4 * lg];
         const int npairs = min(FQC, L - ch * FQC) >> 5;
         for (int u = 0; u < npairs; ++u) {
-            const bf16x8 qa0 = bw_frag(sm.q[32 * u + li][piece]), qa1 = bw_frag(sm.q[32 * u + 16 + li][piece]);
-            const bf16x8 ga0 = bw_frag(sm.g[32 * u + li][piece]), ga1 = bw_frag(sm.g[32 * u + 16 + li][piece]);
-            const bf16x8 qvb = bw_frag(sm.qv[u][lg][li]), gvb = bw_frag(sm.gv[u][lg][li]);
+            const bf16x8 qa0 = bw_frag(st.q[32 * u + li][piece]), qa1 = bw_frag(st.q[32 * u + 16 + li][piece]);
+            const bf16x8 ga0 = bw_frag(st.g[32 * u + li][piece]), ga1 = bw_frag(st.g[32 * u + 16 + li][piece]);
+            const bf16x8 qvb = bw_frag(st.qv[u][lg][li]), gvb = bw_frag(st.gv[u][lg][li]);
             f32x4 dq0 = zero, dq1 = zero;
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
@@ -573,11 +611,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
                         ds[e] = p[e] * d0[e]; ds[4 + e] = p[4 + e] * d1[e];
                     }
                     uint4 phi, plo, dhi, dlo;
-                    bw_split8(p, phi, plo);
-                    bw_split8(ds, dhi, dlo);
+                    bw_split8c(p, phi, plo);
+                    bw_split8c(ds, dhi, dlo);
                     accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(phi), gvb, accv[j], 0, 0, 0);
-                    accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(plo), gvb, accv[j], 0, 0, 0);
                     acck[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(dhi), qvb, acck[j], 0, 0, 0);
+                    accv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(plo), gvb, accv[j], 0, 0, 0);
                     acck[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(dlo), qvb, acck[j], 0, 0, 0);
                     // dS of key li (tile jj of the pair), queries 4 lg .. 4 lg + 3 of query tile 0 / 1, hi and lo
                     uint2* w = tw + jj * (16 * 4);
@@ -586,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
                     w[T_HL] = make_uint2(dlo.x, dlo.y);
                     w[T_HL + T_TILE] = make_uint2(dlo.z, dlo.w);
                 }
-                if (DBG < 2 && pair_ok[jp]) {                         // wave-uniform
+                if (DBG < 2) {
                     // A fragments of dQ += dS^T K: keys 4 lg .. 4 lg + 3 of both tiles of the pair, query li
                     const uint2 h0a = lds_read_tr16(tr0), h0b = lds_read_tr16(tr0 + T_ROW16);
                     const uint2 h1a = lds_read_tr16(tr0 + T_TILE), h1b = lds_read_tr16(tr0 + T_TILE + T_ROW16);
@@ -594,26 +632,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
                     const uint2 l1a = lds_read_tr16(tr0 + T_HL + T_TILE), l1b = lds_read_tr16(tr0 + T_HL + T_TILE + T_ROW16);
                     const bf16x8 kb = bw_frag(kvb[jp]);
                     dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(h0a.x, h0a.y, h0b.x, h0b.y)), kb, dq0, 0, 0, 0);
-                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l0a.x, l0a.y, l0b.x, l0b.y)), kb, dq0, 0, 0, 0);
                     dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(h1a.x, h1a.y, h1b.x, h1b.y)), kb, dq1, 0, 0, 0);
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l0a.x, l0a.y, l0b.x, l0b.y)), kb, dq0, 0, 0, 0);
                     dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l1a.x, l1a.y, l1b.x, l1b.y)), kb, dq1, 0, 0, 0);
                 }
             }
-            // the wave's 64 keys are summed: the two 16-query tiles go to the wave's own slab (columns li < 12), plain stores; the
-            // four slabs are added when the chunk is flushed (LDS float atomics into one shared tile cost ~100 cycles each here)
+            // the wave's 64 keys are summed; the three K pieces (columns li, li + 4, li + 8) are added across lanes, and lanes li < 4
+            // store queries 4 lg .. 4 lg + 3 of both 16-query tiles to the wave's slab, column li
             if (DBG >= 1) {
-                if (dq0[0] + dq1[0] == 123.456f) sm.dq[wave][0][0] = 1.f;       // keep the products alive
-            } else if (li < 12) {
-                float* a = &sm.dq[wave][32 * u + 4 * lg][li];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    a[r * 12] = dq0[r];
-                    a[(16 + r) * 12] = dq1[r];
+                if (dq0[0] + dq1[0] == 123.456f) sm.dq[0][wave][0][0] = 1.f;    // keep the products alive
+            } else {
+                float4 a0, a1;
+                a0.x = bw_piece_sum(dq0[0]); a0.y = bw_piece_sum(dq0[1]); a0.z = bw_piece_sum(dq0[2]); a0.w = bw_piece_sum(dq0[3]);
+                a1.x = bw_piece_sum(dq1[0]); a1.y = bw_piece_sum(dq1[1]); a1.z = bw_piece_sum(dq1[2]); a1.w = bw_piece_sum(dq1[3]);
+                if (li < 4) {
+                    *reinterpret_cast<float4*>(slab + 32 * u) = a0;
+                    *reinterpret_cast<float4*>(slab + 32 * u + 16) = a1;
                 }
             }
         }
+        __syncthreads();
+        // Leave the barrier out of step: wave w starts 16 w cycles late.  Four waves released in the same cycle run the same
+        // instruction stream in exact lockstep and collide on the CU's shared LDS path at every tile (measured: 2.17 -> 1.87 ms for
+        // the whole backward at B = 16, L = 4096; without any barrier -- racy, timing only -- 1.86 ms; 32 w and 64 w cycles: 1.89, 1.94).
+        for (int i = 0; i < wave; ++i) asm volatile("s_nop 15");
     }
-    __syncthreads();
     flush_dq(nchunks - 1);
 
     // dK, dV of this wave's keys (as in the dK/dV kernel)
