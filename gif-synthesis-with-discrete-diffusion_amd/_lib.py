@@ -65,6 +65,7 @@ class LayerDesc(C.Structure):
         ("y", _p), ("x", _p), ("M", _i64), ("L", _i), ("n_embd", _i), ("hidden", _i), ("cvec", _p),
         ("wproj", _p), ("bproj", _p), ("ln2_g", _p), ("ln2_b", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p),
         ("ada", _p), ("t2", _p), ("wqkv", _p), ("bqkv", _p), ("qkv", _p), ("w2_x3", _p), ("wqkv_x3", _p), ("kv_img", _p),
+        ("layer_h2", _p), ("wqkv_h2", _p),
     ]
 
 
@@ -109,6 +110,7 @@ def lib():
         L.gsdd_d3pm_attention_workspace_bytes.restype = _i64
         L.gsdd_d3pm_layer.argtypes = [C.POINTER(LayerDesc), _p]
         L.gsdd_d3pm_layer_pack.argtypes = [_p, _p, _p, _p, _p, _p]
+        L.gsdd_d3pm_layer_pack_h2.argtypes = [_p, _p, _p, _p, _p, _p, _p]
         L.gsdd_d3pm_logits.argtypes = [_p, _i64, _i, _p, _p, _p, _p, _i, _p, _p]
         L.gsdd_d3pm_cross_attention.argtypes = [_p, _p, _p, _i, _i, _i, _i, _p, _p]
         L.gsdd_d3pm_step.argtypes = [C.POINTER(StepDesc), _p]

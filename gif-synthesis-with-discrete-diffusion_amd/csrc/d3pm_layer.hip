@@ -41,6 +41,8 @@ struct LayerArgs {
     float* qkv;                // [48][M][4]
     const uint4* w2_x3;        // optional fragment images (gsdd_d3pm_layer_pack)
     const uint4* wqkv_x3;
+    const uint4* lay_h2;       // optional f16 hi + lo fragment images (gsdd_d3pm_layer_pack_h2)
+    const uint4* wqkv_h2;
     uint4* kimg; uint4* vimg;  // optional: the next block's attention images (k, v go there instead of qkv rows)
 };
 
@@ -969,6 +971,395 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Fourth variant ("h2"): every GEMM operand is an f16 hi + lo pair (22 significant bits) instead of three bf16 pieces, the
+// products hi.hi + hi.lo + lo.hi accumulate in f32 on v_mfma_f32_32x32x16_f16 (each product is exact in the accumulator's
+// format; the dropped lo.lo term is 2^-22 of the product).  Measured against fp64 the result is as accurate as an f32 GEMM
+// with f32 accumulation (tools/emulate_h2.py: rms error 1.3e-8 on 0.16-sized outputs vs 2.3e-8 for numpy's f32 matmul and
+// 4e-9 for the bf16x3 kernel, whose error is the final f32 rounding alone).  What it buys:
+//   * 3 matrix instructions per fragment instead of 6, 2 KB per fragment instead of 3;
+//   * W1, W2 and Wproj (144 KB as h2 images) are ALL LDS-resident: only the next block's Wqkv (48 KB) still streams from L2,
+//     so the MLP loop has no global loads at all (the bf16x3 kernel streams W2, 96 KB per 32-row group, and waits for it);
+//   * 32 fewer live registers in the MLP loop (activation pieces 32 instead of 48, fragments 8 instead of 12): no scratch spills
+//     (the bf16x3 kernel spills 91 dwords per lane, some inside the chunk loop).
+// Subnormal f16 operands do not survive the matrix pipe (measured: unscaled lo pieces gave 3e-5 on the block output, the size of
+// the dropped subnormals), so both sides are scaled by exact powers of two that keep the lo pieces normal: the weights by 2^8 when
+// the images are packed (gsdd_d3pm_layer_pack_h2; lo normal for |w| >= 4.9e-4, below that at most 2.4e-7 of the weight is lost;
+// |w| < 255), the activations by 2^4 -- folded into the LayerNorm gamma / beta, the GELU2 bias and exponent constant, one
+// multiplication for the attention output -- (lo normal for |a| >= 7.8e-3, below that at most 3.8e-6 is lost; |a| < 4094).
+// Accumulators are scaled back by the exact factor 2^-12 in the fused multiply-add that adds the bias.
+typedef _Float16 lh16x8 __attribute__((ext_vector_type(8)));
+struct P2 { lh16x8 p[2]; };
+constexpr float H2_WSCALE = 256.f, H2_ASCALE = 16.f, H2_UNSCALE = 1.f / (256.f * 16.f);
+constexpr int H2_FRAG_U4 = 2 * 64;                            // uint4 per fragment
+constexpr int H2_W2_OFF = 32 * H2_FRAG_U4, H2_WP_OFF = 64 * H2_FRAG_U4, H2_IMG_U4 = 72 * H2_FRAG_U4;    // [W1 | W2 | Wproj] = 144 KB
+constexpr int H2_PAR_OFF = H2_IMG_U4 * 4;                     // float offset of the parameter block
+constexpr int H2_SCR_OFF = H2_PAR_OFF + PAR_N;
+constexpr int H2_LDS_FLOATS = H2_SCR_OFF + 8 * 192;           // 156,416 bytes
+
+// GELU2 of v = v16 / 16, times 16: the power-of-two factors go through the exponent constant and the product exactly
+__device__ __forceinline__ float gelu2_x16(float v16) {
+    return v16 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v16 * (-2.4554669595930157f / 16.f)));
+}
+__device__ __forceinline__ P2 split8h(const float (&v)[8]) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    P2 o;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f2v a = {v[i], v[i + 1]};
+        const h2v hh = __builtin_convertvector(a, h2v);                       // v_cvt_pk_f16_f32 (round to nearest even)
+        const f2v r = a - __builtin_convertvector(hh, f2v);                   // exact
+        const h2v ll = __builtin_convertvector(r, h2v);
+        o.p[0][i] = hh.x; o.p[0][i + 1] = hh.y; o.p[1][i] = ll.x; o.p[1][i + 1] = ll.y;
+    }
+    return o;
+}
+__device__ __forceinline__ P2 split8h_w(const float* row) {   // weights: scaled by 2^8
+    const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
+    const float wv[8] = {lo.x * H2_WSCALE, lo.y * H2_WSCALE, lo.z * H2_WSCALE, lo.w * H2_WSCALE,
+                         hi.x * H2_WSCALE, hi.y * H2_WSCALE, hi.z * H2_WSCALE, hi.w * H2_WSCALE};
+    return split8h(wv);
+}
+__device__ __forceinline__ P2 load_frag2(const uint4* img, int f, int l) {
+    P2 a;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a.p[i] = __builtin_bit_cast(lh16x8, img[(2 * f + i) * 64 + l]);
+    return a;
+}
+__device__ __forceinline__ void mma3(const P2& a, const P2& b, f32x16& acc) {   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[1], b.p[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[0], b.p[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[0], b.p[0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void split_act_h2(const float (&act)[32], P2 (&b)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act[8 * q + j];
+        b[q] = split8h(v);
+    }
+}
+
+// one thread per (fragment, lane): W1 (32 fragments), W2 (32), Wproj (8) -> layer image; Wqkv (24) -> qkv image.  Fragment
+// numbering and element order as in layer_pack_kernel (W1: f = (4 c + q) * 2 + nt, rows 64 c + 32 nt + li).
+__global__ __launch_bounds__(256) void layer_pack_h2_kernel(const float* w1, const float* w2, const float* wproj, const float* wqkv,
+                                                            uint4* lay_h2, uint4* wqkv_h2) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    const int nL = lay_h2 != nullptr ? 72 * 64 : 0, nQ = wqkv_h2 != nullptr ? 24 * 64 : 0;
+    if (u >= nL + nQ) return;
+    const bool is_q = u >= nL;
+    const int v = is_q ? u - nL : u;
+    const int f = v >> 6, l = v & 63, li = l & 31, h = l >> 5;
+    const int nt = f & 1, q = (f >> 1) & 3, c = (f >> 3) & 3;
+    P2 a;
+    if (is_q) a = split8h_w(wqkv + (int64_t)(64 * c + 32 * nt + li) * D + 16 * q + 4 * h);
+    else if (f < 32) a = split8h_w(w1 + (int64_t)(64 * c + 32 * nt + li) * D + 16 * q + 4 * h);
+    else if (f < 64) a = split8h_w(w2 + (int64_t)(32 * nt + li) * HID + 64 * c + 16 * q + 4 * h);
+    else a = split8h_w(wproj + (int64_t)(32 * nt + li) * D + 16 * q + 4 * h);
+    uint4* img = is_q ? wqkv_h2 : lay_h2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) img[(2 * f + i) * 64 + l] = __builtin_bit_cast(uint4, a.p[i]);
+}
+
+// acc[nt] += (fragments f0 .. f0+7 of an LDS image) x the four k-steps of bp; the next fragment's two ds_read_b128 are issued
+// before the current fragment's three MFMAs
+template <bool SWAP = false>   // SWAP: activations as the A operand (result: row in registers, feature on the lane)
+__device__ __forceinline__ void gemm_lds_img_h2(const uint4* img, int f0, int lane, const P2 (&bp)[4], f32x16 (&acc)[2]) {
+    P2 cur = load_frag2(img, f0, lane);
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) {
+        const P2 nxt = load_frag2(img, f0 + (ts < 7 ? ts + 1 : 0), lane);
+        if (SWAP) mma3(bp[ts >> 1], cur, acc[ts & 1]);
+        else mma3(cur, bp[ts >> 1], acc[ts & 1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        cur = nxt;
+    }
+}
+
+template <bool HAS_QKV, bool QKV_ONLY = false>
+__global__ __launch_bounds__(512, 1) void d3pm_layer_h2_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4* iw1 = reinterpret_cast<uint4*>(lds);              // 32 fragments (QKV_ONLY: the 24 fragments of Wqkv)
+    uint4* iw2 = iw1 + H2_W2_OFF;                            // 32 fragments
+    uint4* iwp = iw1 + H2_WP_OFF;                            // 8 fragments
+    float* par = lds + H2_PAR_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    float* scr = lds + H2_SCR_OFF + wave * 192;
+    const uint4* img_qkv = a.wqkv_h2;                        // 24 fragments
+
+    if (!QKV_ONLY) {
+        for (int u = tid; u < H2_IMG_U4; u += 512) iw1[u] = a.lay_h2[u];
+    } else {
+        for (int u = tid; u < 24 * H2_FRAG_U4; u += 512) iw1[u] = img_qkv[u];
+    }
+    for (int i = tid; i < PAR_N; i += 512) {
+        float v;
+        if (QKV_ONLY) v = i >= PAR_BQKV ? a.bqkv[i - PAR_BQKV] : 0.f;
+        else if (i < PAR_G2) v = a.bproj[i];
+        else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2] * H2_ASCALE;          // LN2 output, GELU2 input: carried 16 x
+        else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN] * H2_ASCALE;
+        else if (i < PAR_B2) v = a.b1[i - PAR_B1] * H2_ASCALE;
+        else if (i < PAR_BQKV) v = a.b2[i - PAR_B2];
+        else v = HAS_QKV ? a.bqkv[i - PAR_BQKV] : 0.f;
+        par[i] = v;
+    }
+    __syncthreads();
+
+    const int64_t ngroups = (a.M + 31) / 32;
+    const bool batch_uniform = a.L % 32 == 0;
+    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
+        const int64_t m = grp * 32 + li;
+        const bool valid = m < a.M;
+        const bool full = grp * 32 + 32 <= a.M;
+        const int64_t mc = valid ? m : a.M - 1;
+        const int b = (int)((uint32_t)mc / (uint32_t)a.L);
+        if (batch_uniform) {
+            const int bu = (int)((uint32_t)(grp * 32) / (uint32_t)a.L);
+            if (lane < 16) {
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)bu * D + 4 * lane);
+                *reinterpret_cast<float4*>(scr + 4 * lane) = cv;
+            } else if (HAS_QKV && lane < 48) {
+                const float* tab = a.ada + a.t2[bu] * (2 * D);
+                const float4 tv = *reinterpret_cast<const float4*>(tab + 4 * (lane - 16));
+                *reinterpret_cast<float4*>(scr + 4 * lane) =
+                    make_float4(tv.x * H2_ASCALE, tv.y * H2_ASCALE, tv.z * H2_ASCALE, tv.w * H2_ASCALE);
+            }
+        }
+
+        float act[32], x1[32];
+        f32x16 acc[2];
+        P2 bp[4];
+        float mean, rstd;
+        if (QKV_ONLY) {
+            load_frag(a.x + mc * D, h, x1);
+        } else {
+        // ---- x1 = x + proj(y) + b_proj + cvec[b]
+        load_frag(a.y + mc * D, h, act);
+        load_frag(a.x + mc * D, h, x1);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) act[i] *= H2_ASCALE;
+        split_act_h2(act, bp);
+        zero2(acc);
+        gemm_lds_img_h2(iwp, 0, lane, bp, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bpj = *reinterpret_cast<const float4*>(par + PAR_BPROJ + f);
+                float4 cv;
+                if (batch_uniform) cv = *reinterpret_cast<const float4*>(scr + f);
+                else cv = a.cvec != nullptr ? *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += fmaf(acc[t][r + 0], H2_UNSCALE, bpj.x) + cv.x;
+                x1[16 * t + r + 1] += fmaf(acc[t][r + 1], H2_UNSCALE, bpj.y) + cv.y;
+                x1[16 * t + r + 2] += fmaf(acc[t][r + 2], H2_UNSCALE, bpj.z) + cv.z;
+                x1[16 * t + r + 3] += fmaf(acc[t][r + 3], H2_UNSCALE, bpj.w) + cv.w;
+            }
+        // ---- h = LN2(x1) * gamma + beta
+        row_norm(x1, mean, rstd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 gm = *reinterpret_cast<const float4*>(par + PAR_G2 + f);
+                const float4 bt = *reinterpret_cast<const float4*>(par + PAR_B2LN + f);
+                const int r = 16 * t + 4 * g;
+                act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+            }
+        split_act_h2(act, bp);
+        // ---- MLP in 4 chunks of 64 hidden units, both weight images in LDS
+        f32x16 acc3[2];
+        zero2(acc3);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            zero2(acc);
+            gemm_lds_img_h2(iw1, 8 * c, lane, bp, acc);
+            // GELU2 + split of k-step q + 1 is issued between the MFMAs of k-step q (both tiles)
+            auto make_ub = [&](int q) {
+                const int t = q >> 1, s2 = q & 1;
+                const float4 b0 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s2 + 4 * h);
+                const float4 b1 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s2 + 8 + 4 * h);
+                // 16 x hidden = acc * 2^-8 + 16 b1 (both exact scalings of the unscaled value), 16 x GELU2 out of it
+                constexpr float U16 = H2_UNSCALE * H2_ASCALE;
+                const float u[8] = {gelu2_x16(fmaf(acc[t][8 * s2 + 0], U16, b0.x)), gelu2_x16(fmaf(acc[t][8 * s2 + 1], U16, b0.y)),
+                                    gelu2_x16(fmaf(acc[t][8 * s2 + 2], U16, b0.z)), gelu2_x16(fmaf(acc[t][8 * s2 + 3], U16, b0.w)),
+                                    gelu2_x16(fmaf(acc[t][8 * s2 + 4], U16, b1.x)), gelu2_x16(fmaf(acc[t][8 * s2 + 5], U16, b1.y)),
+                                    gelu2_x16(fmaf(acc[t][8 * s2 + 6], U16, b1.z)), gelu2_x16(fmaf(acc[t][8 * s2 + 7], U16, b1.w))};
+                return split8h(u);
+            };
+            P2 ub = make_ub(0);
+            P2 w2a = load_frag2(iw2, 8 * c, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 8 * c + 2 * q;
+                const P2 w2b = load_frag2(iw2, f0 + 1, lane);
+                const P2 na = load_frag2(iw2, (f0 + 2) & 31, lane);
+                P2 ubn = ub;
+                if (q < 3) ubn = make_ub(q + 1);
+                mma3(w2a, ub, acc3[0]);
+                mma3(w2b, ub, acc3[1]);
+                if (q < 3) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA ...
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);    // ... then a slice of the next operand's VALU work
+                    }
+                }
+                ub = ubn;
+                w2a = na;
+            }
+        }
+        // ---- x2 = x1 + mlp + b2 -> x
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = 32 * t + 8 * g + 4 * h;
+                const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B2 + f);
+                const int r = 4 * g;
+                x1[16 * t + r + 0] += fmaf(acc3[t][r + 0], H2_UNSCALE, bb.x);
+                x1[16 * t + r + 1] += fmaf(acc3[t][r + 1], H2_UNSCALE, bb.y);
+                x1[16 * t + r + 2] += fmaf(acc3[t][r + 2], H2_UNSCALE, bb.z);
+                x1[16 * t + r + 3] += fmaf(acc3[t][r + 3], H2_UNSCALE, bb.w);
+            }
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        } else if (valid) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
+        }
+        }
+        if (HAS_QKV) {
+            // Wqkv fragments come from L2 three tile-steps ahead of their use; the first three are requested before the AdaLN arithmetic
+            P2 wq0, wq1, wq2;
+            if (!QKV_ONLY) { wq0 = load_frag2(img_qkv, 0, lane); wq1 = load_frag2(img_qkv, 1, lane); wq2 = load_frag2(img_qkv, 2, lane); }
+            row_norm(x1, mean, rstd);
+            const float* tab = a.ada + a.t2[b] * (2 * D);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = 32 * t + 8 * g + 4 * h;
+                    float4 gm, bt;
+                    if (batch_uniform) {
+                        gm = *reinterpret_cast<const float4*>(scr + 64 + f);
+                        bt = *reinterpret_cast<const float4*>(scr + 128 + f);
+                    } else {
+                        gm = *reinterpret_cast<const float4*>(tab + f);
+                        bt = *reinterpret_cast<const float4*>(tab + D + f);
+                        gm = make_float4(gm.x * H2_ASCALE, gm.y * H2_ASCALE, gm.z * H2_ASCALE, gm.w * H2_ASCALE);
+                        bt = make_float4(bt.x * H2_ASCALE, bt.y * H2_ASCALE, bt.z * H2_ASCALE, bt.w * H2_ASCALE);
+                    }
+                    const int r = 16 * t + 4 * g;
+                    act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
+                    act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
+                    act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
+                    act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
+                }
+            split_act_h2(act, bp);
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                zero2(acc);
+                // The V image wants eight *rows* of one column in a lane (below), so for it the product is taken the other way
+                // round (activations as the A operand): acc[nt][r] = v[row 8 (r >> 2) + 4 h + (r & 3)][feature 32 nt + li].
+                const bool v_img = c == 2 && a.vimg != nullptr;                         // wave-uniform
+                if (QKV_ONLY) {
+                    if (v_img) gemm_lds_img_h2<true>(iw1, 8 * c, lane, bp, acc);
+                    else gemm_lds_img_h2<false>(iw1, 8 * c, lane, bp, acc);
+                } else {
+#pragma unroll
+                    for (int ts = 0; ts < 8; ++ts) {
+                        const int fn = 8 * c + ts + 3;             // (wraps to the first fragments after the last block: harmless)
+                        const P2 wq3 = load_frag2(img_qkv, fn < 24 ? fn : fn - 24, lane);
+                        if (v_img) mma3(bp[ts >> 1], wq0, acc[ts & 1]);
+                        else mma3(wq0, bp[ts >> 1], acc[ts & 1]);
+                        wq0 = wq1; wq1 = wq2; wq2 = wq3;
+                    }
+                }
+                if (v_img) {
+                    // lane (li, h): head hd = 8 nt + (li >> 2), dim d = li & 3.  Accumulator registers 4 g2 + e and 4 (g2 + 2) + e
+                    // (e = 0..3) are rows 4 g + e of the group's two 16-key tiles for key group g = 2 g2 + h: the eight f16 of
+                    // image entry (pair-tile, g, column) -- three entries for the three pieces of v, and lane d also writes the
+                    // constant column 12 + d (1, 0, 0, 0).  (The group is one 32-key pair-tile of every head: L % 32 == 0.)
+                    const int d = li & 3;
+                    const uint32_t cst = d == 0 ? 0x3C003C00u : 0u;                       // f16 1.0 | 1.0
+                    const int64_t m0 = grp * 32;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int hd = 8 * nt + (li >> 2);
+                        const float bv = par[PAR_BQKV + 128 + 32 * nt + li];
+                        uint4* dst = a.vimg + (((int64_t)hd * a.M + m0) >> 5) * 64;
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            _Float16 p1[8], p2[8], p3[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = fmaf(acc[nt][4 * g2 + (e & 3) + 8 * (e >> 2)], H2_UNSCALE, bv);
+                                const _Float16 a1 = (_Float16)v;
+                                const float r1 = (v - (float)a1) * 2048.f;
+                                const _Float16 a2 = (_Float16)r1;
+                                p1[e] = a1; p2[e] = a2; p3[e] = (_Float16)((r1 - (float)a2) * 2048.f);
+                            }
+                            uint4* e0 = dst + (2 * g2 + h) * 16;
+                            e0[d] = __builtin_bit_cast(uint4, p1);
+                            e0[4 + d] = __builtin_bit_cast(uint4, p2);
+                            e0[8 + d] = __builtin_bit_cast(uint4, p3);
+                            e0[12 + d] = make_uint4(cst, cst, cst, cst);
+                        }
+                    }
+                    continue;
+                }
+                float4 o[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int t = q >> 2, r = 4 * (q & 3);
+                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
+                    o[q] = make_float4(fmaf(acc[t][r + 0], H2_UNSCALE, bb.x), fmaf(acc[t][r + 1], H2_UNSCALE, bb.y),
+                                       fmaf(acc[t][r + 2], H2_UNSCALE, bb.z), fmaf(acc[t][r + 3], H2_UNSCALE, bb.w));
+                }
+                if (c == 1 && a.kimg != nullptr) {
+                    // k of head hd = 8 t + 2 g + h as the attention kernel's pre-split image (row = hd * M + m): two 16-byte stores
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int hd = 8 * (q >> 2) + 2 * (q & 3) + h;
+                            const float vals[4] = {o[q].x, o[q].y, o[q].z, o[q].w};
+                            kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
+                        }
+                    }
+                } else if (full) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                } else if (valid) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // to_logits: logits[m][:] = W LN(x[m]) + b  (nn.LayerNorm(64) + nn.Linear(64 -> K), transformer_utils.py:353-356,442).
 // Same transposed-GEMM register layout: a wave owns 32 rows, normalises them in registers once and sweeps all K
 // output features; W streams through LDS in 256-feature chunks shared by the 8 waves (double-buffered).
@@ -1136,19 +1527,40 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
         attr_done = true;
     }
     a.w2_x3 = reinterpret_cast<const uint4*>(d->w2_x3); a.wqkv_x3 = reinterpret_cast<const uint4*>(d->wqkv_x3);
+    a.lay_h2 = reinterpret_cast<const uint4*>(d->layer_h2); a.wqkv_h2 = reinterpret_cast<const uint4*>(d->wqkv_h2);
+    // GSDD_LAYER=f32 | x3 | x3p | h2 forces a variant (A/B; read per call); default: the f16 hi + lo images when the caller packed
+    // them, else the bf16x3 images, else on-the-fly splits
+    const char* force = getenv("GSDD_LAYER");
+    const bool have_x3 = (qkv_only || d->w2_x3 != nullptr) && (!has_qkv || d->wqkv_x3 != nullptr);
+    const bool have_h2 = (qkv_only || d->layer_h2 != nullptr) && (!has_qkv || d->wqkv_h2 != nullptr);
+    int variant;                                               // 0 f32, 1 bf16x3 split on the fly, 2 bf16x3 images, 3 f16 hi + lo images
+    if (force == nullptr) variant = have_h2 ? 3 : (have_x3 ? 2 : 1);
+    else if (force[0] == 'f') variant = 0;
+    else if (force[0] == 'h') variant = 3;
+    else variant = force[2] == 'p' ? 2 : 1;
+    if (qkv_only && variant < 2) variant = have_h2 ? 3 : 2;
+    GSDD_CHECK_ARG(variant != 3 || have_h2, "GSDD_LAYER=h2 needs the gsdd_d3pm_layer_pack_h2 images");
+    GSDD_CHECK_ARG(variant != 2 || have_x3, "the bf16x3 image kernel needs the gsdd_d3pm_layer_pack images");
     a.kimg = a.vimg = nullptr;
     if (has_qkv && d->kv_img != nullptr) {
-        GSDD_CHECK_ARG((d->y == nullptr || d->w2_x3 != nullptr) && d->wqkv_x3 != nullptr && d->L % 32 == 0 && getenv("GSDD_LAYER") == nullptr,
-                       "kv_img needs the packed-weight kernel (both fragment images) and L % 32 == 0");
+        GSDD_CHECK_ARG(variant >= 2 && d->L % 32 == 0, "kv_img needs a packed-weight kernel (fragment images) and L % 32 == 0");
         a.kimg = reinterpret_cast<uint4*>(d->kv_img);
         a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
     }
-    // GSDD_LAYER=f32 | x3 | x3p forces a variant (A/B); default: fragment images when the caller packed them, else on-the-fly splits
-    static const char* force = getenv("GSDD_LAYER");
-    const bool have_img = d->w2_x3 != nullptr && (!has_qkv || d->wqkv_x3 != nullptr);
-    const int variant = qkv_only ? 2 : force == nullptr ? (have_img ? 2 : 1) : (force[0] == 'f' ? 0 : ((force[2] == 'p' && have_img) ? 2 : 1));
-    GSDD_CHECK_ARG(!qkv_only || (has_qkv && d->wqkv_x3 != nullptr), "y = NULL (q|k|v stage only) needs qkv and the wqkv image");
-    if (variant == 0) {
+    GSDD_CHECK_ARG(!qkv_only || has_qkv, "y = NULL (q|k|v stage only) needs qkv");
+    if (variant == 3) {
+        const size_t ldsh = (size_t)H2_LDS_FLOATS * sizeof(float);
+        static bool attr_h = false;
+        if (!attr_h) {
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+            attr_h = true;
+        }
+        if (qkv_only) hipLaunchKernelGGL((d3pm_layer_h2_kernel<true, true>), dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
+        else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_h2_kernel<true>, dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(d3pm_layer_h2_kernel<false>, dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
+    } else if (variant == 0) {
         if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     } else if (variant == 1) {
@@ -1167,6 +1579,16 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
         else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3p_kernel<true>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(d3pm_layer_x3p_kernel<false>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
     }
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_d3pm_layer_pack_h2(const float* w1, const float* w2, const float* wproj, const float* wqkv, void* layer_h2,
+                                       void* wqkv_h2, void* stream) {
+    GSDD_CHECK_ARG((layer_h2 == nullptr || (w1 && w2 && wproj)) && (wqkv_h2 == nullptr || wqkv) && (layer_h2 || wqkv_h2), "null pointer");
+    const int n = (layer_h2 != nullptr ? 72 * 64 : 0) + (wqkv_h2 != nullptr ? 24 * 64 : 0);
+    hipLaunchKernelGGL(layer_pack_h2_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2, wproj, wqkv,
+                       reinterpret_cast<uint4*>(layer_h2), reinterpret_cast<uint4*>(wqkv_h2));
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

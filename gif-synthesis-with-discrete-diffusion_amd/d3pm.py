@@ -154,13 +154,20 @@ class Text2ImageTransformer(nn.Module):
         return p
 
     def fragment_images(self, stream=None):
-        """bf16x3 weight fragment images of the fused layer kernel, made on the sampler's first use after the weights changed
-        (the training step re-packs every iteration and never needs them).  Enqueued on `stream`: every stream that reads them
-        must be ordered after it (sample() builds them on the caller's stream before its lanes fork)."""
+        """Weight fragment images of the fused layer kernel, made on the sampler's first use after the weights changed (the training
+        step re-packs every iteration and never needs them): f16 hi + lo images by default, the bf16x3 images when GSDD_LAYER=x3p
+        asks for that kernel (A/B).  Enqueued on `stream`: every stream that reads them must be ordered after it (sample() builds
+        them on the caller's stream before its lanes fork)."""
         layers = self.packed()["layers"]
-        if self.n_embd == 64 and layers and "w2_x3" not in layers[0] and layers[0]["w1"].shape[0] == 256:
+        if not (self.n_embd == 64 and layers and layers[0]["w1"].shape[0] == 256):
+            return
+        if os.environ.get("GSDD_LAYER", "h2") == "x3p":
+            if "w2_x3" not in layers[0]:
+                for lay in layers:
+                    lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
+        elif "lay_h2" not in layers[0]:
             for lay in layers:
-                lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
+                lay["lay_h2"], lay["wqkv_h2"] = ops.d3pm_layer_pack_h2(lay["w1"], lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
 
     # ------------------------------------------------------------------ one denoiser pass on the HIP path
     def cond_vectors(self, cond):
@@ -200,8 +207,9 @@ class Text2ImageTransformer(nn.Module):
             # The fused layer kernel writes k and v straight into the attention workspace as the matrix-pipe kernel's pre-split
             # images (no f32 k|v rows, no pre-split pass); block 0 runs its q|k|v stage alone on the embedding
             attn_ws = ws.get("attn")
-            img = (attn_ws is not None and L % 32 == 0 and all("wqkv_x3" in l and "w2_x3" in l for l in layers)
-                   and not any(os.environ.get(e) for e in ("GSDD_LAYER", "GSDD_ATTN_V3")))
+            img = (attn_ws is not None and L % 32 == 0 and os.environ.get("GSDD_LAYER", "h2") in ("h2", "x3p")
+                   and all(("lay_h2" in l and "wqkv_h2" in l) or ("w2_x3" in l and "wqkv_x3" in l) for l in layers)
+                   and not os.environ.get("GSDD_ATTN_V3"))
             x0, q0 = (x[:M1], ws["qkv0"]) if share0 else (x, qkv)
             if img:
                 ops.d3pm_layer(None, x0, L, None, nxt=layers[0], t2=t2, qkv=q0, kv_img=attn_ws, stream=stream)

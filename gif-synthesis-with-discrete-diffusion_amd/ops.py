@@ -191,9 +191,11 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None
         d.wproj, d.bproj, d.ln2_g, d.ln2_b = ptr(lay["wproj"]), ptr(lay["bproj"]), ptr(lay["g2"]), ptr(lay["b2"])
         d.w1, d.b1, d.w2, d.b2 = ptr(lay["w1"]), ptr(lay["bb1"]), ptr(lay["w2"]), ptr(lay["bb2"])
         d.w2_x3 = ptr(lay.get("w2_x3"))
+        d.layer_h2 = ptr(lay.get("lay_h2"))
     if nxt is not None:
         d.ada, d.t2, d.wqkv, d.bqkv, d.qkv = ptr(nxt["ada1"]), ptr(t2), ptr(nxt["wqkv"]), ptr(nxt["bqkv"]), ptr(qkv)
         d.wqkv_x3 = ptr(nxt.get("wqkv_x3"))
+        d.wqkv_h2 = ptr(nxt.get("wqkv_h2"))
         d.kv_img = ptr(kv_img)
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
 
@@ -207,6 +209,17 @@ def d3pm_layer_pack(w2, wproj, wqkv, stream=None):
     wqkv_x3 = torch.empty((WQKV_X3_BYTES,), dtype=torch.uint8, device=w2.device)
     check(lib().gsdd_d3pm_layer_pack(ptr(w2), ptr(wproj), ptr(wqkv), ptr(lay_x3), ptr(wqkv_x3), stream_ptr(stream)))
     return lay_x3, wqkv_x3
+
+
+LAYER_H2_BYTES, WQKV_H2_BYTES = 72 * 2 * 1024, 24 * 2 * 1024
+
+
+def d3pm_layer_pack_h2(w1, w2, wproj, wqkv, stream=None):
+    """f16 hi + lo fragment images for the fused layer kernel: (w1 + w2 + wproj of a block, wqkv of a block)."""
+    lay_h2 = torch.empty((LAYER_H2_BYTES,), dtype=torch.uint8, device=w2.device)
+    wqkv_h2 = torch.empty((WQKV_H2_BYTES,), dtype=torch.uint8, device=w2.device)
+    check(lib().gsdd_d3pm_layer_pack_h2(ptr(w1), ptr(w2), ptr(wproj), ptr(wqkv), ptr(lay_h2), ptr(wqkv_h2), stream_ptr(stream)))
+    return lay_h2, wqkv_h2
 
 
 def d3pm_logits(x, g, b, w, bias, out, stream=None):

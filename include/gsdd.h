@@ -198,6 +198,10 @@ typedef struct {
     void* kv_img;               /* optional (needs both images above and L % 32 == 0): the attention workspace of the next     */
                                 /* block.  k and v are then written there as the matrix-pipe kernel's pre-split images instead */
                                 /* of f32 rows of qkv, and gsdd_d3pm_attention is called with k = v = NULL (no prep pass)      */
+    const void* layer_h2;       /* optional: gsdd_d3pm_layer_pack_h2 images (f16 hi + lo MFMA fragments) of this block's w1, w2 and */
+    const void* wqkv_h2;        /* wproj, and of the next block's wqkv.  Preferred over the bf16x3 images when given: all three    */
+                                /* weight matrices of the block are then LDS-resident and every product is 3 matrix instructions   */
+                                /* instead of 6; as accurate as an f32 GEMM with f32 accumulation (22-bit operands, exact products) */
 } gsdd_layer_desc;
 int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
 /* Pre-split w2 [64][256] + wproj [64][64] (-> layer_x3, GSDD_LAYER_X3_BYTES) and wqkv [192][64] (-> wqkv_x3,
@@ -205,6 +209,12 @@ int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
 #define GSDD_LAYER_X3_BYTES (40 * 3 * 1024)
 #define GSDD_LAYER_WQKV_X3_BYTES (24 * 3 * 1024)
 int gsdd_d3pm_layer_pack(const float* w2, const float* wproj, const float* wqkv, void* layer_x3, void* wqkv_x3, void* stream);
+/* The f16 hi + lo images: w1 [256][64] + w2 [64][256] + wproj [64][64] -> layer_h2 (GSDD_LAYER_H2_BYTES), wqkv [192][64] -> wqkv_h2
+ * (GSDD_LAYER_WQKV_H2_BYTES); either image may be NULL (then its sources may be too).  Weights must be below 255 in magnitude. */
+#define GSDD_LAYER_H2_BYTES (72 * 2 * 1024)
+#define GSDD_LAYER_WQKV_H2_BYTES (24 * 2 * 1024)
+int gsdd_d3pm_layer_pack_h2(const float* w1, const float* w2, const float* wproj, const float* wqkv, void* layer_h2, void* wqkv_h2,
+                            void* stream);
 
 /* to_logits: out[m][:] = W LayerNorm(x[m]) + bias  (nn.LayerNorm + nn.Linear, transformer_utils.py:353-356, 442);
  * x: [M][64], w: [K][64], out: [M][K] rows (the reference's (B,K,L) is a transposed view of this). */

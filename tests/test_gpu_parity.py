@@ -447,10 +447,11 @@ def test_near_tie_stress_vectors(G, golden):
     parity_report("near_tie_stress", rec)
 
 
-def test_fused_layer_variants_agree(G):
-    """gsdd_d3pm_layer with the pre-split weight images (default when Text2ImageTransformer packs them), without them
-    (weights split on the fly), and writing k/v as attention images instead of f32 rows: same block output; the image path is
-    checked through the attention kernel that consumes it."""
+def test_fused_layer_variants_agree(G, monkeypatch):
+    """gsdd_d3pm_layer with the f16 hi + lo weight images (default when Text2ImageTransformer packs them), with the bf16x3 images
+    (GSDD_LAYER=x3p), without images (weights split on the fly), and writing k/v as attention images instead of f32 rows: same
+    block output, each also against an fp64 evaluation of the block; the image path is checked through the attention kernel that
+    consumes it."""
     torch.manual_seed(11)
     B2, L, H, Dm = 4, 64, 16, 64
     d = G.DalleMaskImageEmbedding(num_embed=33, spatial_size=[8, 8], embed_dim=Dm)
@@ -460,36 +461,58 @@ def test_fused_layer_variants_agree(G):
         for p_ in tr.parameters():
             p_.mul_(8.0)                      # N(0, 0.02) init would make every block nearly the identity
     lay0, lay1 = (dict(l) for l in tr.packed()["layers"])
+    plain0, plain1 = dict(lay0), dict(lay1)
+    x3_0, x3_1 = dict(lay0), dict(lay1)
     for lay in (lay0, lay1):                  # the sampler makes these on first use
+        lay["lay_h2"], lay["wqkv_h2"] = G.ops.d3pm_layer_pack_h2(lay["w1"], lay["w2"], lay["wproj"], lay["wqkv"])
+    for lay in (x3_0, x3_1):
         lay["w2_x3"], lay["wqkv_x3"] = G.ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
     M = B2 * L
     y = torch.randn(M, Dm, device="cuda")
     x_in = torch.randn(M, Dm, device="cuda")
     cv = torch.randn(B2, Dm, device="cuda")
     t2 = torch.tensor([0, 3, 9, 5], dtype=torch.int64, device="cuda")
-    plain0 = {k: v for k, v in lay0.items() if not k.endswith("_x3")}
-    plain1 = {k: v for k, v in lay1.items() if not k.endswith("_x3")}
-    outs = []
-    for l0, l1 in ((lay0, lay1), (plain0, plain1)):
+    # fp64 evaluation of the same block tail (Block.forward's tail + the next block's AdaLN and q|k|v)
+    f = lambda k_, l_: l_[k_].detach().double()
+    x1 = x_in.double() + y.double() @ f("wproj", lay0).T + f("bproj", lay0) + cv.double().repeat_interleave(L, 0)
+    ln = torch.nn.functional.layer_norm(x1, (Dm,), f("g2", lay0), f("b2", lay0), 1e-5)
+    hid = ln @ f("w1", lay0).T + f("bb1", lay0)
+    x2 = x1 + (hid * torch.sigmoid(1.702 * hid)) @ f("w2", lay0).T + f("bb2", lay0)
+    tab = f("ada1", lay1)[t2].repeat_interleave(L, 0)
+    an = torch.nn.functional.layer_norm(x2, (Dm,), None, None, 1e-5) * tab[:, :Dm] + tab[:, Dm:]
+    qkv64 = (an @ f("wqkv", lay1).T + f("bqkv", lay1)).reshape(M, 3 * H, 4).permute(1, 0, 2)
+    outs, errs = [], {}
+    for name, l0, l1 in (("h2", lay0, lay1), ("x3p", x3_0, x3_1), ("x3", plain0, plain1)):
         x = x_in.clone()
         qkv = torch.zeros(3 * H, M, 4, device="cuda")
         G.ops.d3pm_layer(y, x, L, l0, cvec=cv, nxt=l1, t2=t2, qkv=qkv)
         outs.append((x, qkv))
-    torch.testing.assert_close(outs[0][0], outs[1][0], atol=2e-5, rtol=0)
-    torch.testing.assert_close(outs[0][1], outs[1][1], atol=2e-5, rtol=0)
-    # k, v as images: attention on (q rows, images) == attention on the f32 q, k, v rows
-    ws = G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda"))
-    x = x_in.clone()
-    qkv2 = torch.zeros(3 * H, M, 4, device="cuda")
-    G.ops.d3pm_layer(y, x, L, lay0, cvec=cv, nxt=lay1, t2=t2, qkv=qkv2, kv_img=ws)
-    torch.testing.assert_close(x, outs[0][0], atol=0, rtol=0)
-    assert torch.equal(qkv2[:H], outs[0][1][:H]) and not qkv2[H:].any()          # q rows written, k/v rows untouched
-    a_img = torch.empty(M, Dm, device="cuda")
-    a_ref = torch.empty(M, Dm, device="cuda")
-    G.ops.d3pm_attention(qkv2[:H], None, None, B2, L, H, a_img, ws=ws)
-    q, k, v = outs[0][1][:H], outs[0][1][H:2 * H], outs[0][1][2 * H:]
-    G.ops.d3pm_attention(q, k, v, B2, L, H, a_ref, ws=G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda")))
-    torch.testing.assert_close(a_img, a_ref, atol=1e-6, rtol=0)
+        errs[name] = {"x": float((x.double() - x2).abs().max()), "qkv": float((qkv.double() - qkv64).abs().max())}
+    errs["max_abs"] = {"x": float(x2.abs().max()), "hidden": float(hid.abs().max()), "qkv": float(qkv64.abs().max())}
+    parity_report("fused_layer_vs_fp64", errs)
+    # (weights x 8: hidden units reach ~30 and GELU2 runs on the bare v_exp_f32 / v_rcp_f32, 1 ulp each -- the x error of every
+    # variant is that, not the operand format; q|k|v of the normalised stream is the sharper check)
+    assert all(e["x"] < 6e-5 and e["qkv"] < 1e-5 for n_, e in errs.items() if n_ != "max_abs"), errs
+    for o in outs[1:]:                        # (|x| reaches 75 here: 1e-6 relative is one ulp)
+        torch.testing.assert_close(outs[0][0], o[0], atol=4e-5, rtol=1e-6)
+        torch.testing.assert_close(outs[0][1], o[1], atol=2e-5, rtol=0)
+    # k, v as images: attention on (q rows, images) == attention on the f32 q, k, v rows -- for both image kernels
+    for (l0, l1), ref, env in (((lay0, lay1), outs[0], None), ((x3_0, x3_1), outs[1], "x3p")):
+        if env:
+            monkeypatch.setenv("GSDD_LAYER", env)
+        ws = G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda"))
+        x = x_in.clone()
+        qkv2 = torch.zeros(3 * H, M, 4, device="cuda")
+        G.ops.d3pm_layer(y, x, L, l0, cvec=cv, nxt=l1, t2=t2, qkv=qkv2, kv_img=ws)
+        torch.testing.assert_close(x, ref[0], atol=0, rtol=0)
+        assert torch.equal(qkv2[:H], ref[1][:H]) and not qkv2[H:].any()          # q rows written, k/v rows untouched
+        a_img = torch.empty(M, Dm, device="cuda")
+        a_ref = torch.empty(M, Dm, device="cuda")
+        G.ops.d3pm_attention(qkv2[:H], None, None, B2, L, H, a_img, ws=ws)
+        q, k, v = ref[1][:H], ref[1][H:2 * H], ref[1][2 * H:]
+        G.ops.d3pm_attention(q, k, v, B2, L, H, a_ref, ws=G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda")))
+        torch.testing.assert_close(a_img, a_ref, atol=1e-6, rtol=0)
+        monkeypatch.delenv("GSDD_LAYER", raising=False)
 
 
 @pytest.mark.parametrize("L,spatial", [(48, [8, 8]), (96, [16, 8])])

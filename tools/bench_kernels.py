@@ -96,8 +96,11 @@ def main():
         tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
                                             content_spatial_size=[64, 64], diffusion_step=100).cuda()
         p = tr.packed()
-        for lay in p["layers"]:               # bf16x3 weight fragment images (the sampler makes them on first use)
-            lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
+        for lay in p["layers"]:               # weight fragment images (the sampler makes them on first use): f16 hi + lo, or GSDD_LAYER=x3p
+            if os.environ.get("GSDD_LAYER") == "x3p":
+                lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"])
+            else:
+                lay["lay_h2"], lay["wqkv_h2"] = ops.d3pm_layer_pack_h2(lay["w1"], lay["w2"], lay["wproj"], lay["wqkv"])
         x = torch.randn((M, D), device=dev); y = torch.randn((M, D), device=dev)
         qkv = torch.empty((3 * H, M, 4), device=dev)
         cv = torch.randn((B2, D), device=dev)
@@ -105,6 +108,9 @@ def main():
         ms = timeit(lambda: ops.d3pm_layer(y, x, L, p["layers"][0], cvec=cv, nxt=p["layers"][1], t2=t2, qkv=qkv))
         fl = 2.0 * M * (64 * 64 + 2 * 64 * 256 + 64 * 192)
         print(f"fused layer (proj+mlp+next qkv): {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+        aws = ops.d3pm_attention_workspace(B2, L, H, dev)
+        ms = timeit(lambda: ops.d3pm_layer(y, x, L, p["layers"][0], cvec=cv, nxt=p["layers"][1], t2=t2, qkv=qkv, kv_img=aws))
+        print(f"fused layer (proj+mlp+next q, K/V images): {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
         ms = timeit(lambda: ops.d3pm_layer(y, x, L, p["layers"][0], cvec=cv))
         fl = 2.0 * M * (64 * 64 + 2 * 64 * 256)
         print(f"fused layer (proj+mlp, last):    {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
