@@ -78,7 +78,7 @@ def attention_roofline(dm, B, L, H, device, K, reps=3):
     tf = flops / (ms * 1e-3) / 1e12
     traffic = None
     if (B2, L, H) == (32, 4096, 16):
-        traffic = (2 * 82033.7 + 33294.3) * 1024      # profiles/r1_pmc_traffic.csv, d3pm_attention_v4_kernel<384>
+        traffic = (2 * 82043.7 + 33846.8) * 1024      # profiles/r2_pmc_traffic.csv, d3pm_attention_v4_kernel<384;8>
     return {"bound": "mfma", "kernel": f"d3pm_attention_v4_kernel<384, {P_MODES[os.environ.get('GSDD_ATTN_P', 'a8')][0]}>",
             "achieved": round(tf, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
@@ -112,6 +112,15 @@ def cpu_baseline(args, dm, vq, L):
     return {"value": 1.0 / per_video, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 guided reverse step at B=1 L={L} ({t_step:.2f} s) x{T} + 1 decode ({t_dec:.2f} s), "
                       "torch-CPU oracle"}
+
+
+LAYER_ARITH = {
+    "h2": "per-block GEMMs (proj, MLP, next q|k|v): operands as f16 hi + lo (22 bits, every product exact in the f32 accumulator; "
+          "as accurate as an f32 GEMM: DESIGN.md section 4; GSDD_LAYER=x3p selects the bf16x3 kernel)",
+    "x3p": "per-block GEMMs as 3-way bf16 splits too (GSDD_LAYER=x3p)",
+    "x3": "per-block GEMMs as 3-way bf16 splits, split on the fly (GSDD_LAYER=x3)",
+    "f32": "per-block GEMMs on v_mfma_f32_32x32x2_f32 (GSDD_LAYER=f32)",
+}
 
 
 def trained_like_weights(dm, seed=1):
@@ -220,8 +229,9 @@ def main():
                                    f"{args.grid[1] * 8}x{args.grid[2] * 8}",
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "hipgraph": not args.no_graph,
-                       "arith": "f32 results; GEMM / QK^T operands as error-free 3-way bf16 splits on the matrix pipe (dropped terms "
-                                "< 2^-24); softmax P: " + P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][1]},
+                       "arith": "f32 results; QK^T, to_logits and VQ-VAE GEMM operands as error-free 3-way bf16 splits on the matrix "
+                                "pipe (dropped terms < 2^-24); " + LAYER_ARITH[os.environ.get("GSDD_LAYER", "h2")] +
+                                "; softmax P: " + P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][1]},
             "ranks": {"seconds_max": round(max(rank_s), 4), "seconds_min": round(min(rank_s), 4),
                       "videos_per_s_per_rank": [round(B * args.steps / s_, 4) for s_ in rank_s]},
         }
