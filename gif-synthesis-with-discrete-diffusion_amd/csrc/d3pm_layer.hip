@@ -1090,10 +1090,17 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_h2_kernel(const LayerArgs a
     float* scr = lds + H2_SCR_OFF + wave * 192;
     const uint4* img_qkv = a.wqkv_h2;                        // 24 fragments
 
-    if (!QKV_ONLY) {
-        for (int u = tid; u < H2_IMG_U4; u += 512) iw1[u] = a.lay_h2[u];
-    } else {
-        for (int u = tid; u < 24 * H2_FRAG_U4; u += 512) iw1[u] = img_qkv[u];
+    // the weight images go global -> registers -> LDS with every load in flight before the first store (a copy loop pays one L2
+    // round trip per iteration: 18 of them were 5 us of an 84 us kernel)
+    {
+        constexpr int NCP = (QKV_ONLY ? 24 * H2_FRAG_U4 : H2_IMG_U4) / 512;
+        static_assert(H2_IMG_U4 % 512 == 0 && (24 * H2_FRAG_U4) % 512 == 0, "image copy assumes whole rounds of the workgroup");
+        const uint4* src = QKV_ONLY ? img_qkv : a.lay_h2;
+        uint4 tmp[NCP];
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) tmp[i] = src[tid + 512 * i];
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) iw1[tid + 512 * i] = tmp[i];
     }
     for (int i = tid; i < PAR_N; i += 512) {
         float v;
@@ -1138,6 +1145,10 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_h2_kernel(const LayerArgs a
             load_frag(a.x + mc * D, h, x1);
         } else {
         // ---- x1 = x + proj(y) + b_proj + cvec[b]
+        // (Tried and measured slower, each through spills of the 256-register budget: requesting the next group's rows during this
+        // group's q|k|v stage, 77 -> 108 us -- vmcnt also retires in order, so every wait for a Wqkv fragment behind those loads waits
+        // for their HBM latency; holding q and k in registers so that all stores follow the last product, 194 us; requesting Wqkv a
+        // whole 8-fragment block at a time ahead of the previous block's stores, 110 us.)
         load_frag(a.y + mc * D, h, act);
         load_frag(a.x + mc * D, h, x1);
 #pragma unroll

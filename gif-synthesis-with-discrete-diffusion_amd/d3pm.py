@@ -161,7 +161,16 @@ class Text2ImageTransformer(nn.Module):
         layers = self.packed()["layers"]
         if not (self.n_embd == 64 and layers and layers[0]["w1"].shape[0] == 256):
             return
-        if os.environ.get("GSDD_LAYER", "h2") == "x3p":
+        want = os.environ.get("GSDD_LAYER", "h2")
+        if want == "h2" and "lay_h2" not in layers[0] and "w2_x3" not in layers[0]:
+            # the f16 images hold 2^8 w: a weight of 255 or more would overflow them (checked once per weight set; such a model takes
+            # the bf16x3 kernel, which has f32's range)
+            wmax = max(float(lay[k].abs().max()) for lay in layers for k in ("w1", "w2", "wproj", "wqkv"))
+            if not wmax < 255.0:
+                want = "x3p"
+        elif want == "h2" and "w2_x3" in layers[0]:
+            want = "x3p"
+        if want == "x3p":
             if "w2_x3" not in layers[0]:
                 for lay in layers:
                     lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)

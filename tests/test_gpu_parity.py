@@ -537,6 +537,29 @@ def test_denoiser_ragged_lengths_match_oracle(G, L, spatial):
     torch.testing.assert_close(got.cpu(), want, atol=LOGIT_TOL, rtol=0)
 
 
+def test_layer_kernel_weight_range_guard(G):
+    """The default fused-layer kernel holds weights as f16 images of 2^8 w, so a weight of 255 or more must not take it: such a model is
+    routed to the bf16x3 kernel (f32 range) and still matches the oracle."""
+    from oracle import d3pm as od
+    torch.manual_seed(5)
+    K, B, L = 32, 2, 64
+    d = G.DalleMaskImageEmbedding(num_embed=K, spatial_size=[8, 8], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                 content_spatial_size=[8, 8], diffusion_step=10)
+    with torch.no_grad():
+        tr.blocks[0].mlp[0].weight[3, 5] = 300.0          # one hidden unit with an absurd input weight
+        tr.blocks[0].mlp[2].weight[:, 3] = 0.0            # ... which feeds nothing, so the output stays moderate
+    sd = {"transformer." + k: v.detach().clone() for k, v in tr.state_dict().items()}
+    tok = torch.randint(0, K + 1, (B, L))
+    cond = torch.randn(B, 1, 512)
+    t = torch.tensor([1, 7])
+    want = od.denoiser(tok, cond, t, sd)
+    got = tr.cuda()(tok.cuda(), cond.cuda(), t.cuda())
+    lay = tr.packed()["layers"][0]
+    assert "w2_x3" in lay and "lay_h2" not in lay
+    torch.testing.assert_close(got.cpu(), want, atol=LOGIT_TOL, rtol=0)
+
+
 # ----------------------------------------------------------------------------- the attention kernel's arithmetic modes
 def test_attention_arithmetic_modes(G, golden, monkeypatch):
     """GSDD_ATTN_P: the default (adaptive lo half for L >= 2048, hi + lo everywhere below) and the most exact mode (22) meet the bars --
