@@ -971,6 +971,124 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Row GEMMs of the training step (gsdd_rows_linear): out[m][:] = x[m] W^T + bias [+ bvec[batch]] [+ residual[m]] for the skinny
+// layers of a block (64 -> 64 / 192 / 256 and 192 / 256 -> 64, forward and data gradients).  The generic GEMM writes such outputs
+// at 1.2-1.5 TB/s (4-byte stores, weights re-split by every 128-row block: 51-62 us for 64 -> 192 at 65,536 rows); here the weights
+// are a bf16x3 fragment image made once per optimiser step (gsdd_rows_linear_pack), LDS-resident for the launch, the row is on the
+// lane as in the fused layer kernel, and a lane stores 16 bytes of one row at a time.  bf16x3, not f16 pairs: gradients need f32's range.
+// Image: fragment f = ((nb * KC + kc) * 4 + q) * 2 + nt  (64-output block nb, 64-input chunk kc, k-step q, 32-row half nt), piece p,
+// lane l -> uint4 (3 f + p) * 64 + l; element j of lane (li, h): W[64 nb + 32 nt + li][64 kc + 16 q + 8 (j >> 2) + 4 h + (j & 3)].
+struct RowsLinArgs {
+    const float* x; int64_t M; int K, N;
+    const uint4* img;
+    const float* bias;         // [N] or null
+    const float* bvec;         // [M / rows_per_batch][N] or null
+    int rows_per_batch;
+    const float* residual;     // [M][N] or null
+    float* out;                // [M][N], or head-major [N / 4][M][4]
+    int head_major;
+};
+struct RowsPackDesc {          // one weight matrix -> one image; lives in device memory (gsdd_rows_linear_pack_many)
+    const float* w;            // [rows][ld] row-major
+    int n_out, n_in;           // the image's matrix W' is n_out x n_in
+    int ld;
+    int transpose;             // 0: W'[n][k] = w[n * ld + k];  1: W'[n][k] = w[k * ld + n]  (the data-gradient GEMM's operand)
+    uint4* img;
+};
+
+__global__ __launch_bounds__(256) void rows_linear_pack_kernel(const RowsPackDesc* descs, int n_desc) {
+    const RowsPackDesc d = descs[blockIdx.y];
+    const int KC = d.n_in >> 6;
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= (d.n_out >> 6) * KC * 8 * 64) return;
+    const int f = u >> 6, l = u & 63, li = l & 31, h = l >> 5;
+    const int nt = f & 1, q = (f >> 1) & 3, blk = f >> 3;
+    const int nb = blk / KC, kc = blk - nb * KC;
+    const int n = 64 * nb + 32 * nt + li;
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 64 * kc + 16 * q + 8 * (j >> 2) + 4 * h + (j & 3);
+        wv[j] = d.transpose ? d.w[(int64_t)k * d.ld + n] : d.w[(int64_t)n * d.ld + k];
+    }
+    store_frag(d.img, f, l, split8(wv));
+}
+
+template <int KC, int NB>      // K = 64 KC inputs, N = 64 NB outputs; KC == 1 or NB == 1
+__global__ __launch_bounds__(512, 1) void rows_linear_kernel(const RowsLinArgs a) {
+    static_assert(KC == 1 || NB == 1, "one of the two dimensions is a single 64-wide block");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4* img = reinterpret_cast<uint4*>(lds);
+    constexpr int IMG_U4 = NB * KC * 8 * IMG_FRAG_U4;
+    float* bias = lds + IMG_U4 * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    {   // image -> LDS, every load in flight before the first store
+        constexpr int NCP = IMG_U4 / 512;
+        static_assert(IMG_U4 % 512 == 0, "whole rounds of the workgroup");
+        uint4 tmp[NCP];
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) tmp[i] = a.img[tid + 512 * i];
+#pragma unroll
+        for (int i = 0; i < NCP; ++i) img[tid + 512 * i] = tmp[i];
+    }
+    if (tid < 64 * NB) bias[tid] = a.bias != nullptr ? a.bias[tid] : 0.f;
+    __syncthreads();
+
+    const int64_t ngroups = (a.M + 31) / 32;
+    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
+        const int64_t m = grp * 32 + li;
+        const bool valid = m < a.M;
+        const int64_t mc = valid ? m : a.M - 1;
+        const float* bv = a.bvec != nullptr ? a.bvec + (mc / a.rows_per_batch) * a.N : nullptr;
+        float act[32];
+        f32x16 acc[2];
+        P3 bp[4];
+        auto finish = [&](int nb) {       // acc -> + bias [+ bvec] [+ residual] -> out: 8 runs of 4 features of row m
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 64 * nb + 32 * t + 8 * g + 4 * h, r = 4 * g;
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+                    float4 o = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
+                    if (bv != nullptr) {
+                        const float4 c = *reinterpret_cast<const float4*>(bv + n);
+                        o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+                    }
+                    if (a.residual != nullptr) {
+                        const float4 c = *reinterpret_cast<const float4*>(a.residual + mc * a.N + n);
+                        o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+                    }
+                    if (valid) {
+                        if (a.head_major) *reinterpret_cast<float4*>(a.out + ((int64_t)(n >> 2) * a.M + m) * 4) = o;
+                        else *reinterpret_cast<float4*>(a.out + m * a.N + n) = o;
+                    }
+                }
+        };
+        if (KC == 1) {
+            load_frag(a.x + mc * a.K, h, act);
+            split_act(act, bp);
+#pragma unroll 1
+            for (int nb = 0; nb < NB; ++nb) {
+                zero2(acc);
+                gemm_lds_img(img, 8 * nb, lane, bp, acc);
+                finish(nb);
+            }
+        } else {
+            zero2(acc);
+#pragma unroll 1
+            for (int kc = 0; kc < KC; ++kc) {
+                load_frag(a.x + mc * a.K + 64 * kc, h, act);
+                split_act(act, bp);
+                gemm_lds_img(img, 8 * kc, lane, bp, acc);
+            }
+            finish(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Fourth variant ("h2"): every GEMM operand is an f16 hi + lo pair (22 significant bits) instead of three bf16 pieces, the
 // products hi.hi + hi.lo + lo.hi accumulate in f32 on v_mfma_f32_32x32x16_f16 (each product is exact in the accumulator's
 // format; the dropped lo.lo term is 2^-22 of the product).  Measured against fp64 the result is as accurate as an f32 GEMM
@@ -1591,6 +1709,48 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
         else hipLaunchKernelGGL(d3pm_layer_x3p_kernel<false>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
     }
     GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_rows_linear_pack_many(const void* descs_dev, int n_desc, int max_out, int max_in, void* stream) {
+    GSDD_CHECK_ARG(descs_dev != nullptr && n_desc > 0 && max_out > 0 && max_in > 0 && max_out % 64 == 0 && max_in % 64 == 0, "bad args");
+    const int units = (max_out >> 6) * (max_in >> 6) * 8 * 64;
+    hipLaunchKernelGGL(rows_linear_pack_kernel, dim3((units + 255) / 256, n_desc), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const RowsPackDesc*>(descs_dev), n_desc);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+template <int KC, int NB>
+static int rows_linear_launch(const RowsLinArgs& a, void* stream) {
+    const size_t ldsb = (size_t)NB * KC * 8 * IMG_FRAG_U4 * 16 + (size_t)64 * NB * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)rows_linear_kernel<KC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr = true;
+    }
+    const int64_t ngroups = (a.M + 31) / 32;
+    const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
+    hipLaunchKernelGGL((rows_linear_kernel<KC, NB>), dim3(grid), dim3(512), ldsb, (hipStream_t)stream, a);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_rows_linear(const float* x, int64_t M, int n_in, const void* image, int n_out, const float* bias, const float* bvec,
+                                int rows_per_batch, const float* residual, float* out, int head_major, void* stream) {
+    GSDD_CHECK_ARG(x && image && out && M > 0, "null pointer");
+    GSDD_CHECK_ARG(bvec == nullptr || rows_per_batch > 0, "bvec needs rows_per_batch");
+    RowsLinArgs a;
+    a.x = x; a.M = M; a.K = n_in; a.N = n_out; a.img = reinterpret_cast<const uint4*>(image); a.bias = bias; a.bvec = bvec;
+    a.rows_per_batch = rows_per_batch; a.residual = residual; a.out = out; a.head_major = head_major;
+    if (n_in == 64 && n_out == 64) return rows_linear_launch<1, 1>(a, stream);
+    if (n_in == 64 && n_out == 128) return rows_linear_launch<1, 2>(a, stream);
+    if (n_in == 64 && n_out == 192) return rows_linear_launch<1, 3>(a, stream);
+    if (n_in == 64 && n_out == 256) return rows_linear_launch<1, 4>(a, stream);
+    if (n_in == 128 && n_out == 64) return rows_linear_launch<2, 1>(a, stream);
+    if (n_in == 192 && n_out == 64) return rows_linear_launch<3, 1>(a, stream);
+    if (n_in == 256 && n_out == 64) return rows_linear_launch<4, 1>(a, stream);
+    GSDD_CHECK_ARG(false, "gsdd_rows_linear: shapes are 64 -> 64 / 128 / 192 / 256 and 128 / 192 / 256 -> 64");
     return GSDD_OK;
 }
 

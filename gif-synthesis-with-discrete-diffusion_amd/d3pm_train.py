@@ -5,6 +5,8 @@ torch.autograd of the CPU oracle; the sampling path does not depend on anything 
 Reference: MultistageTextMotionModel.allsplit_step (src/models/multistage_text_motion_model.py:170-206: zero_grad ->
 manual_backward -> Adam(lr 1e-4, betas (0.5, 0.999))) around DiffusionTransformer._train_loss
 (src/models/motionencoder/diffusion_transformer.py:391-457); DDP gradient averaging = configs/trainer/default.yaml:8."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -16,6 +18,64 @@ from .parallel import GradReducer, broadcast_module, world_size
 BUCKET_LAYERS = 5          # blocks per gradient bucket: 19 blocks + head + embeddings -> 5 all-reduces of ~2.7 MB each
 
 
+class _LinearImages:
+    """bf16x3 fragment images (gsdd_rows_linear) of every block's weight matrices and of their transposes (the data-gradient
+    operands), all refreshed by ONE launch per optimiser step.  The descriptor table points at the parameters themselves (the
+    optimisers update them in place); `refresh` rebuilds it if a parameter has moved."""
+    NAMES = ("qkv", "qkv_t", "proj", "proj_t", "w1", "w1_t", "w2", "w2_t")
+
+    def __init__(self, tr):
+        self.tr = tr
+        self.ptrs = None
+
+    @staticmethod
+    def _pieces(blk):
+        a, m = blk.attn1, blk.mlp
+        q, k, v = a.query.weight, a.key.weight, a.value.weight
+        # name -> (n_out, n_in, [(weight, rows of the image matrix it fills, columns, transpose, fragment offset)])
+        return {
+            "qkv": (192, 64, [(w, 64, 64, 0, 8 * j) for j, w in enumerate((q, k, v))]),
+            "qkv_t": (64, 192, [(w, 64, 64, 1, 8 * j) for j, w in enumerate((q, k, v))]),
+            "proj": (64, 64, [(a.proj.weight, 64, 64, 0, 0)]),
+            "proj_t": (64, 64, [(a.proj.weight, 64, 64, 1, 0)]),
+            "w1": (256, 64, [(m[0].weight, 256, 64, 0, 0)]),
+            "w1_t": (64, 256, [(m[0].weight, 64, 256, 1, 0)]),
+            "w2": (64, 256, [(m[2].weight, 64, 256, 0, 0)]),
+            "w2_t": (256, 64, [(m[2].weight, 256, 64, 1, 0)]),
+        }
+
+    def _build(self):
+        import numpy as np
+        dev = self.tr.blocks[0].mlp[0].weight.device
+        per_block = sum(ops.rows_linear_image_bytes(no, ni) for no, ni, _ in self._pieces(self.tr.blocks[0]).values())
+        self.buf = torch.empty((len(self.tr.blocks) * per_block,), dtype=torch.uint8, device=dev)
+        rows, self.images, off = [], [], 0
+        for blk in self.tr.blocks:
+            imgs = {}
+            for name, (no, ni, pieces) in self._pieces(blk).items():
+                nbytes = ops.rows_linear_image_bytes(no, ni)
+                imgs[name] = self.buf[off:off + nbytes]
+                for w, po, pi, tr_, frag in pieces:
+                    assert w.is_contiguous() and w.dtype == torch.float32
+                    rows.append((w.data_ptr(), po, pi, w.shape[1], tr_, self.buf.data_ptr() + off + frag * 3 * 1024))
+                off += nbytes
+            self.images.append(imgs)
+        table = np.array(rows, dtype=np.dtype([("w", "<u8"), ("n_out", "<i4"), ("n_in", "<i4"), ("ld", "<i4"), ("transpose", "<i4"),
+                                               ("img", "<u8")]))
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+        self.n_desc = len(rows)
+        self.ptrs = [r[0] for r in rows]
+
+    def _current_ptrs(self):
+        return [w.data_ptr() for blk in self.tr.blocks for _, _, pieces in self._pieces(blk).values() for w, *_ in pieces]
+
+    def refresh(self):
+        if self.ptrs is None or self.ptrs != self._current_ptrs():
+            self._build()
+        ops.rows_linear_pack_many(self.table, self.n_desc, 256, 256)
+        return self.images
+
+
 class D3PMTrainer:
     def __init__(self, dm, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
         self.dm, self.lr, self.betas, self.eps = dm, lr, betas, eps
@@ -23,6 +83,7 @@ class D3PMTrainer:
         self.state = {}
         self.reducer = GradReducer()
         self._synced = False
+        self._images = None
 
     def _sync_start(self):
         """Once, before the first data-parallel step: every rank takes rank 0's parameters and buffers (what DDP does at wrap time)."""
@@ -47,8 +108,33 @@ class D3PMTrainer:
         x = torch.empty((M, D), **f)
         ops.d3pm_embed(xt, p["emb"], p["pos"], x)
         aws = ops.d3pm_attention_workspace(B, L, H, dev) if L % 32 == 0 else None     # pre-split K/V images (matrix-pipe forward)
-        for lay in p["layers"]:
+        # the block's row GEMMs run on gsdd_rows_linear (weights as fragment images, refreshed once per step) when the block has
+        # the north-star widths; other widths take the generic GEMM
+        fast = D == 64 and p["layers"] and p["layers"][0]["w1"].shape[0] == 256 and os.environ.get("GSDD_TRAIN_LINEAR") != "gemm"
+        if fast:
+            if self._images is None:
+                self._images = _LinearImages(tr)
+            imgs = self._images.refresh()
+        sv["imgs"] = imgs if fast else None
+        for li_, lay in enumerate(p["layers"]):
             s = {"x_in": x}
+            if fast:
+                im = imgs[li_]
+                s["stats1"], s["hn"] = ops.ln_fwd(x, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], sel=t, gstride=2 * D,
+                                                  rows_per_batch=L)
+                s["qkv"] = ops.rows_linear(s["hn"], im["qkv"], 3 * D, torch.empty((3 * H, M, 4), **f), bias=lay["bqkv"], head_major=True)
+                s["y"], s["lse"] = torch.empty((M, D), **f), torch.empty((H * M,), **f)
+                ops.d3pm_attention_train(s["qkv"][0:H], s["qkv"][H:2 * H], s["qkv"][2 * H:], B, L, H, s["y"], s["lse"], ws=aws)
+                s["v2"] = ops.small_linear(flat, lay["wv2"], lay["bv2"])
+                cvec = ops.small_linear(s["v2"], lay["wproj2"], lay["bproj2"])
+                s["x1"] = ops.rows_linear(s["y"], im["proj"], D, torch.empty((M, D), **f), bias=lay["bproj"], bvec=cvec,
+                                          rows_per_batch=L, residual=x)
+                s["stats2"], s["h2"] = ops.ln_fwd(s["x1"], lay["g2"], lay["b2"])
+                s["a"] = ops.rows_linear(s["h2"], im["w1"], 4 * D, torch.empty((M, 4 * D), **f), bias=lay["bb1"])
+                s["u"] = ops.gelu2(s["a"])
+                x = ops.rows_linear(s["u"], im["w2"], D, torch.empty((M, D), **f), bias=lay["bb2"], residual=s["x1"])
+                sv["layers"].append(s)
+                continue
             s["stats1"], s["hn"] = ops.ln_fwd(x, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], sel=t, gstride=2 * D,
                                               rows_per_batch=L)          # AdaLayerNorm: statistics + normalised rows in one pass
             s["qkv"] = ops.linear(s["hn"], lay["wqkv"], torch.empty((3 * H, M, 4), **f), bias=lay["bqkv"], out_mode=2)
@@ -135,11 +221,14 @@ class D3PMTrainer:
             pre = f"blocks.{i}."
             blk = tr.blocks[i]
             # ---- MLP
+            im = sv["imgs"][i] if sv.get("imgs") is not None else None
+            lin_t = (lambda dy_, name, w_, n_out: ops.rows_linear(dy_, im[name], n_out, torch.empty((B * L, n_out), **f))) if im is not None \
+                else (lambda dy_, name, w_, n_out: ops.linear(dy_, tw(w_), torch.empty((B * L, n_out), **f)))
             ops.wgrad(dx, s["u"], z(pre + "mlp.2.weight", lay["w2"]), z(pre + "mlp.2.bias", lay["bb2"]))
-            du = ops.linear(dx, tw(lay["w2"]), torch.empty_like(s["u"]))
+            du = lin_t(dx, "w2_t", lay["w2"], s["u"].shape[1])
             da = ops.gelu2(s["a"], du)
             ops.wgrad(da, s["h2"], z(pre + "mlp.0.weight", lay["w1"]), z(pre + "mlp.0.bias", lay["bb1"]))
-            dh2 = ops.linear(da, tw(lay["w1"]), torch.empty((B * L, D), **f))
+            dh2 = lin_t(da, "w1_t", lay["w1"], D)
             dx1 = ops.ln_bwd(dh2, s["x1"], s["stats2"], lay["g2"], dx_in=dx, dgamma=z(pre + "ln2.weight", lay["g2"]),
                              dbeta=z(pre + "ln2.bias", lay["b2"]), gacc_stride=D)
             # ---- attention output projection + the broadcast cross-attention vector
@@ -154,7 +243,7 @@ class D3PMTrainer:
                             ("ln1_1.emb.weight", blk.ln1_1.emb.weight), ("ln1_1.linear.weight", blk.ln1_1.linear.weight),
                             ("ln1_1.linear.bias", blk.ln1_1.linear.bias)):
                 z(pre + nm, ref)                # softmax over a single key: exactly zero gradient
-            dy = ops.linear(dx1, tw(lay["wproj"]), torch.empty((B * L, D), **f))
+            dy = lin_t(dx1, "proj_t", lay["wproj"], D)
             # ---- self-attention
             qkv = s["qkv"]
             dqkv = ops.d3pm_attention_bwd(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], s["y"], dy, s["lse"], B, L, H, ws=bws)
@@ -165,7 +254,7 @@ class D3PMTrainer:
                 g[pre + f"attn1.{nm}.weight"] = wq[j * D:(j + 1) * D]
                 g[pre + f"attn1.{nm}.bias"] = bq[j * D:(j + 1) * D]
             del g[pre + "_wqkv"], g[pre + "_bqkv"]
-            dhn = ops.linear(dqkv, tw(lay["wqkv"]), torch.empty((B * L, D), **f))
+            dhn = lin_t(dqkv, "qkv_t", lay["wqkv"], D)
             dtab = torch.zeros((B, 2 * D), **f)
             dx = ops.ln_bwd(dhn, s["x_in"], s["stats1"], lay["ada1"].view(-1), sel=t, gstride=2 * D, rows_per_batch=L,
                             dx_in=dx1, dgamma=dtab, dbeta=dtab.view(-1)[D:], gacc_stride=2 * D, acc_by_batch=True)

@@ -222,6 +222,22 @@ def d3pm_layer_pack_h2(w1, w2, wproj, wqkv, stream=None):
     return lay_h2, wqkv_h2
 
 
+def rows_linear_image_bytes(n_out, n_in):
+    return (n_out // 64) * (n_in // 64) * 8 * 3 * 1024
+
+
+def rows_linear_pack_many(table, n_desc, max_out, max_in, stream=None):
+    """table: device bytes holding n_desc descriptors {w ptr, n_out, n_in, ld, transpose, image ptr} (include/gsdd.h)."""
+    check(lib().gsdd_rows_linear_pack_many(ptr(table), n_desc, max_out, max_in, stream_ptr(stream)))
+
+
+def rows_linear(x, image, n_out, out, *, bias=None, bvec=None, rows_per_batch=0, residual=None, head_major=False, stream=None):
+    """out[m][:] = x[m] W'^T + bias [+ bvec[batch]] [+ residual[m]] with W' as a gsdd_rows_linear_pack_many image (training step)."""
+    check(lib().gsdd_rows_linear(ptr(x), x.shape[0], x.shape[1], ptr(image), n_out, ptr(bias), ptr(bvec), rows_per_batch,
+                                 ptr(residual), ptr(out), int(head_major), stream_ptr(stream)))
+    return out
+
+
 def d3pm_logits(x, g, b, w, bias, out, stream=None):
     check(lib().gsdd_d3pm_logits(ptr(x), x.shape[0], x.shape[1], ptr(g), ptr(b), ptr(w), ptr(bias), w.shape[0], ptr(out),
                                  stream_ptr(stream)))

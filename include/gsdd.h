@@ -216,6 +216,18 @@ int gsdd_d3pm_layer_pack(const float* w2, const float* wproj, const float* wqkv,
 int gsdd_d3pm_layer_pack_h2(const float* w1, const float* w2, const float* wproj, const float* wqkv, void* layer_h2, void* wqkv_h2,
                             void* stream);
 
+/* Row GEMMs of a block in the training step: out[m][:] = x[m] W'^T + bias [+ bvec[m / rows_per_batch]] [+ residual[m]], n_in -> n_out
+ * one of 64 -> 64 / 128 / 192 / 256 or 128 / 192 / 256 -> 64, with W' (n_out x n_in) given as a bf16x3 fragment image of
+ * GSDD_ROWS_LINEAR_IMAGE_BYTES(n_out, n_in) bytes.  Replaces the nn.Linear calls of Block / FullAttention (transformer_utils.py:48-50,
+ * 60, 258-263) and their data gradients in D3PMTrainer; head_major: out is [n_out / 4][M][4] (q | k | v).
+ * gsdd_rows_linear_pack_many fills n_desc images in one launch from a DEVICE array of
+ *   struct { const float* w; int n_out, n_in, ld, transpose; void* image; }   (transpose: W'[n][k] = w[k * ld + n], the data gradient's
+ * operand; else W'[n][k] = w[n * ld + k]); max_out / max_in: the largest n_out / n_in among them. */
+#define GSDD_ROWS_LINEAR_IMAGE_BYTES(n_out, n_in) ((n_out) / 64 * ((n_in) / 64) * 8 * 3 * 1024)
+int gsdd_rows_linear_pack_many(const void* descs_dev, int n_desc, int max_out, int max_in, void* stream);
+int gsdd_rows_linear(const float* x, int64_t M, int n_in, const void* image, int n_out, const float* bias, const float* bvec,
+                     int rows_per_batch, const float* residual, float* out, int head_major, void* stream);
+
 /* to_logits: out[m][:] = W LayerNorm(x[m]) + bias  (nn.LayerNorm + nn.Linear, transformer_utils.py:353-356, 442);
  * x: [M][64], w: [K][64], out: [M][K] rows (the reference's (B,K,L) is a transposed view of this). */
 int gsdd_d3pm_logits(const float* x, int64_t M, int n_embd, const float* ln_g, const float* ln_b, const float* w,

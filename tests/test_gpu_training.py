@@ -212,3 +212,38 @@ def test_d3pm_forward_backward_through_autograd_bridge(G, golden):
     for name, prm in dm.transformer.named_parameters():
         assert prm.grad is not None, name
         torch.testing.assert_close(prm.grad, 2.0 * want[name], rtol=1e-5, atol=1e-8, msg=lambda s, n=name: f"{n}: {s}")
+
+
+@pytest.mark.parametrize("n_in,n_out", [(64, 64), (64, 128), (64, 192), (64, 256), (128, 64), (192, 64), (256, 64)])
+def test_rows_linear_matches_fp64(G, n_in, n_out):
+    """gsdd_rows_linear (the block's row GEMMs in the training step, weights as bf16x3 fragment images): every shape, plain and
+    transposed images, bias / per-batch vector / residual epilogues, head-major output, a row count that is not a multiple of 32 --
+    against an fp64 product.  Gradients run through it too, hence operands far outside f16's range."""
+    import numpy as np
+    ops = G.ops
+    torch.manual_seed(n_in + n_out)
+    Lb, Bn = 40, 3                                  # 120 rows: three full 32-row groups and one of 24
+    M = Lb * Bn
+    x = torch.randn(M, n_in, device="cuda") * 1e-6  # gradient-sized values
+    x[::7] *= 1e9
+    w = torch.randn(n_out, n_in, device="cuda") * 0.1
+    wt = w.t().contiguous()                          # [n_in][n_out]: the image of its transpose is W again
+    bias = torch.randn(n_out, device="cuda")
+    bvec = torch.randn(Bn, n_out, device="cuda")
+    res = torch.randn(M, n_out, device="cuda")
+    nbytes = ops.rows_linear_image_bytes(n_out, n_in)
+    imgs = torch.empty((2, nbytes), dtype=torch.uint8, device="cuda")
+    rows = [(w.data_ptr(), n_out, n_in, n_in, 0, imgs[0].data_ptr()), (wt.data_ptr(), n_out, n_in, n_out, 1, imgs[1].data_ptr())]
+    table = np.array(rows, dtype=np.dtype([("w", "<u8"), ("n_out", "<i4"), ("n_in", "<i4"), ("ld", "<i4"), ("transpose", "<i4"), ("img", "<u8")]))
+    ops.rows_linear_pack_many(torch.from_numpy(table.view(np.uint8).copy()).cuda(), 2, n_out, n_in)
+    assert torch.equal(imgs[0], imgs[1])
+    want = x.double() @ w.double().t()
+    scale = float(want.abs().max())
+    out = ops.rows_linear(x, imgs[0], n_out, torch.empty(M, n_out, device="cuda"))
+    assert float((out.double() - want).abs().max()) < 1e-6 * scale
+    full = want + bias.double() + bvec.double().repeat_interleave(Lb, 0) + res.double()
+    out = ops.rows_linear(x, imgs[1], n_out, torch.empty(M, n_out, device="cuda"), bias=bias, bvec=bvec, rows_per_batch=Lb, residual=res)
+    assert float((out.double() - full).abs().max()) < 1e-6 * max(scale, float(full.abs().max()))
+    hm = ops.rows_linear(x, imgs[0], n_out, torch.empty(n_out // 4, M, 4, device="cuda"), bias=bias, head_major=True)
+    ref = (want + bias.double()).reshape(M, n_out // 4, 4).permute(1, 0, 2)
+    assert float((hm.double() - ref).abs().max()) < 1e-6 * max(scale, float(ref.abs().max()))
