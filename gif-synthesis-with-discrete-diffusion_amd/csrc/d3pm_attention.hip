@@ -758,8 +758,13 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     uint4* vp = kp + rows * 2;
     hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
     GSDD_CHECK_LAUNCH();
-    // the training forward always carries P as hi + lo: its output and log-sum-exp feed the backward, where the adaptive mode's
-    // extra 1e-5 shows up as noise on the gradients that are mathematically zero (it would save 1 ms of an 83 ms step)
+    // GSDD_ATTN_TRAIN_P=a8 lets the training forward use the sampler's adaptive lo half at L >= 2048 (default: hi + lo everywhere --
+    // its output and log-sum-exp feed the backward, where the adaptive mode's extra 1e-5 is noise on gradients that are mathematically zero)
+    const char* tp = getenv("GSDD_ATTN_TRAIN_P");
+    if (tp != nullptr && tp[0] == 'a' && L >= 2048)
+        hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
+                           out, lse);
+    else
     hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
                        out, lse);
     GSDD_CHECK_LAUNCH();
