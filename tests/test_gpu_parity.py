@@ -537,6 +537,23 @@ def test_denoiser_ragged_lengths_match_oracle(G, L, spatial):
     torch.testing.assert_close(got.cpu(), want, atol=LOGIT_TOL, rtol=0)
 
 
+def test_layer_kernel_variant_without_its_images_fails_loudly(G, monkeypatch):
+    """Forcing an image kernel (GSDD_LAYER=h2 / x3p) on a call that carries no images of that kind is an error, not a silent switch."""
+    torch.manual_seed(3)
+    d = G.DalleMaskImageEmbedding(num_embed=33, spatial_size=[8, 8], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=64, block_activate="GELU2",
+                                 content_spatial_size=[8, 8], diffusion_step=10).cuda()
+    lay = dict(tr.packed()["layers"][0])
+    x = torch.randn(64, 64, device="cuda")
+    y = torch.randn(64, 64, device="cuda")
+    for forced in ("h2", "x3p"):
+        monkeypatch.setenv("GSDD_LAYER", forced)
+        with pytest.raises(G.GsddError):
+            G.ops.d3pm_layer(y, x.clone(), 64, lay)
+    monkeypatch.delenv("GSDD_LAYER")
+    G.ops.d3pm_layer(y, x.clone(), 64, lay)       # no images, no forcing: the split-on-the-fly kernel
+
+
 def test_layer_kernel_weight_range_guard(G):
     """The default fused-layer kernel holds weights as f16 images of 2^8 w, so a weight of 255 or more must not take it: such a model is
     routed to the bf16x3 kernel (f32 range) and still matches the oracle."""
