@@ -486,18 +486,14 @@ __global__ __launch_bounds__(256) void d3pm_train_finalize_kernel(TrainFinArgs a
             same0 += (a.x0_recon[p] == a.x0[p]) ? 1.f : 0.f;
             same1 += (a.xt1_recon[p] == a.xt[p]) ? 1.f : 0.f;
         }
-        float vals[5] = {kl, nll, aux, same0, same1};
+        // block sums: wave shuffles, then the four wave totals through LDS (two barriers per sample instead of forty-five)
+        float vals[5] = {wave_sum(kl), wave_sum(nll), wave_sum(aux), wave_sum(same0), wave_sum(same1)};
         float tot[5];
-        for (int q = 0; q < 5; ++q) {
-            red[0][tid] = vals[q];
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) red[0][tid] += red[0][tid + o];
-                __syncthreads();
-            }
-            tot[q] = red[0][0];
-            __syncthreads();
-        }
+        if ((tid & 63) == 0)
+            for (int q = 0; q < 5; ++q) red[0][(tid >> 6) * 8 + q] = vals[q];
+        __syncthreads();
+        for (int q = 0; q < 5; ++q) tot[q] = (red[0][q] + red[0][8 + q]) + (red[0][16 + q] + red[0][24 + q]);
+        __syncthreads();
         if (tid == 0) {
             const int64_t t = a.t_dev[b];
             const float m0 = (t == 0) ? 1.f : 0.f;
