@@ -144,22 +144,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, int ldy, co
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const bool do_bias = db != nullptr && blockIdx.z == 0;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);              // column sums of this thread's 4 columns ((tid & 15) * 4) over its rows
+    // A slab's 2 x 8 float4 per thread are requested together and unconditionally (clamped addresses; what lies outside the matrix is
+    // zeroed when it is staged), and the next slab's are in flight during this slab's MFMAs.  (With the loads under their bounds tests
+    // inside the staging loop the kernel paid eight memory round trips per slab, one after the other: 65 us where the bytes need 28.)
+    const int c4 = (tid & 15) * 4, rb = tid >> 4;              // this thread's column run and first row of a slab (then every 16th)
+    const bool y_ok = n0 + c4 < N, x_ok = k0 + c4 < K;
+    const int cy = y_ok ? n0 + c4 : 0, cx = x_ok ? k0 + c4 : 0;
+    float4 vy[8], vx[8];
+    auto load_slab = [&](int64_t r0) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t rr = r0 + rb + 16 * it;
+            const int64_t rc = rr < M ? rr : M - 1;
+            vy[it] = *reinterpret_cast<const float4*>(dY + rc * ldy + cy);
+            vx[it] = *reinterpret_cast<const float4*>(X + rc * ldx + cx);
+        }
+    };
+    const int64_t first = (int64_t)blockIdx.x * slabs * WG_ROWS;
+    if (first < M) load_slab(first);
     for (int sl = 0; sl < slabs; ++sl) {
         const int64_t r0 = ((int64_t)blockIdx.x * slabs + sl) * WG_ROWS;
         if (r0 >= M) break;
         __syncthreads();
-        for (int i = tid; i < WG_ROWS * 16; i += 256) {
-            const int r = i >> 4, c = (i & 15) * 4;
-            float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vx = vy;
-            if (r0 + r < M) {
-                if (n0 + c < N) vy = *reinterpret_cast<const float4*>(dY + (r0 + r) * ldy + n0 + c);
-                if (k0 + c < K) vx = *reinterpret_cast<const float4*>(X + (r0 + r) * ldx + k0 + c);
-            }
-            *reinterpret_cast<float4*>(&sy[r][c]) = vy;
-            *reinterpret_cast<float4*>(&sx[r][c]) = vx;
-            cs.x += vy.x; cs.y += vy.y; cs.z += vy.z; cs.w += vy.w;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = rb + 16 * it;
+            const bool row_ok = r0 + r < M;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 y4 = (row_ok && y_ok) ? vy[it] : z, x4 = (row_ok && x_ok) ? vx[it] : z;
+            *reinterpret_cast<float4*>(&sy[r][c4]) = y4;
+            *reinterpret_cast<float4*>(&sx[r][c4]) = x4;
+            cs.x += y4.x; cs.y += y4.y; cs.z += y4.z; cs.w += y4.w;
         }
         __syncthreads();
+        if (sl + 1 < slabs && r0 + WG_ROWS < M) load_slab(r0 + WG_ROWS);
 #pragma unroll 8
         for (int s = 0; s < WG_ROWS / 2; ++s) {
             const float a = sy[2 * s + lh][wn * 32 + li];          // A[i = n][k = m]
