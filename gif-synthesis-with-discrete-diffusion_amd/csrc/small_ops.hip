@@ -135,15 +135,47 @@ __global__ __launch_bounds__(256) void nearest_code_kernel(const float* z, int64
     }
     float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
     int bidx[4] = {0, 0, 0, 0};
+    // A 64-code chunk of the codebook is NC_T * E / 4 float4: up to NC_STG per thread, requested together and unconditionally (rows past
+    // K are clamped and zeroed when staged) and one chunk ahead, so that they arrive behind the distance arithmetic.  (With the loads
+    // under their bounds test inside the staging loop every chunk paid eight L2 round trips in a row -- more than its arithmetic.)
+    constexpr int NC_STG = 8;                              // E <= 128 (host-checked); wider rows take the plain loop
+    const int nstg = (NC_T * (E >> 2) + 255) / 256;
+    const bool pipelined = nstg <= NC_STG;
+    float4 stg[NC_STG];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NC_STG; ++it) {
+            const int i = tid + 256 * it;
+            if (it < nstg) {                               // uniform
+                const int ic = i < NC_T * (E >> 2) ? i : 0;
+                const int r = ic / (E >> 2), c = (ic % (E >> 2)) * 4;
+                const int kr = k0 + r < K ? k0 + r : K - 1;
+                stg[it] = *reinterpret_cast<const float4*>(cb + (int64_t)kr * E + c);
+            }
+        }
+    };
+    if (pipelined) load_chunk(0);
     for (int k0 = 0; k0 < K; k0 += NC_T) {
         __syncthreads();
-        for (int i = tid; i < NC_T * (E >> 2); i += 256) {
-            const int r = i / (E >> 2), c = (i % (E >> 2)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + r < K) v = *reinterpret_cast<const float4*>(cb + (int64_t)(k0 + r) * E + c);
-            *reinterpret_cast<float4*>(&sc[r * EP + c]) = v;
+        if (pipelined) {
+#pragma unroll
+            for (int it = 0; it < NC_STG; ++it) {
+                const int i = tid + 256 * it;
+                if (it < nstg && i < NC_T * (E >> 2)) {
+                    const int r = i / (E >> 2), c = (i % (E >> 2)) * 4;
+                    *reinterpret_cast<float4*>(&sc[r * EP + c]) = k0 + r < K ? stg[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        } else {
+            for (int i = tid; i < NC_T * (E >> 2); i += 256) {
+                const int r = i / (E >> 2), c = (i % (E >> 2)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + r < K) v = *reinterpret_cast<const float4*>(cb + (int64_t)(k0 + r) * E + c);
+                *reinterpret_cast<float4*>(&sc[r * EP + c]) = v;
+            }
         }
         __syncthreads();
+        if (pipelined && k0 + NC_T < K) load_chunk(k0 + NC_T);
         float dot[4][4], en[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
