@@ -51,44 +51,119 @@ def build_models(args, device):
     return dm.to(device).eval(), vq.to(device).eval(), L
 
 
-def attention_roofline(dm, B, L, H, device, K, reps=3):
-    """Dominant kernel (self-attention, head dim 4) timed live with HIP events on its launch stream, in situ: after the timed
-    region `reps` more denoiser passes run eagerly on the sampler's own stream and workspace, with an event pair around every
-    full-batch attention launch (the ABI call; from block 1 on K and V arrive pre-split from the fused layer kernel, so this is
-    the attention kernel alone), so the kernel sees the operands, cache
-    state and clocks of the real loop (a back-to-back loop of attention launches alone clocks ~6 % lower).  Algorithmic
-    FLOPs = 16*L^2 per (sample, head) (QK^T 2*4 + PV 2*4 per score).  `traffic` = HBM bytes per launch from the rocprofv3
-    PMC passes committed under profiles/ (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
-    ws, (condv, Te, rep, B) = dm._last_ws, dm._last_run            # one lane of the sampler (B = its sub-batch)
-    B2 = rep * B
-    st = dm._stream
-    tok = torch.randint(0, K, (B, L), device=device)
-    tok[torch.rand((B, L), device=device) < 0.5] = K                  # half [MASK], like the middle of a chain
-    t2 = torch.full((B2,), dm.num_timesteps // 2, dtype=torch.int64, device=device)
-    events = []
+def profile_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest profiles/r*_pmc_traffic.csv that lists it (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, committed with the round; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
+    MI355X_MICROARCH.md).  -> (bytes, file name) or (None, None): the number is read, never typed in."""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.csv")), reverse=True):
+        with open(f) as fh:
+            rows = [r for r in csv.DictReader(l for l in fh if not l.startswith("#"))]
+        for r in rows:
+            if r["kernel"].replace(" ", "") == kernel.replace(", ", ";").replace(" ", ""):
+                return (2 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) * 1024, os.path.basename(f)
+    return None, None
+
+
+def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
+    """Per-launch timing of the kernels of a reverse step, live, with HIP events on the launch stream, in situ: right after the
+    timed region `reps` more guided denoiser passes run eagerly as ONE full batch of 2B rows on one stream (the timed region
+    itself may run two concurrent lanes, where a launch overlaps the other lane's kernels and its duration stops measuring the
+    kernel), with an event pair around every launch of interest: the operands, cache state and clocks are the loop's.
+    Dominant kernel = self-attention (head dim 4): algorithmic FLOPs = 16*L^2 per (sample, head) (QK^T 2*4 + PV 2*4 per score);
+    from block 1 on K and V arrive pre-split from the fused layer kernel, so the event pair brackets the attention kernel alone.
+    -> (roofline of the dominant kernel, roofline_families: fused layer (GEMM family), logits, posterior step, decode)."""
+    from gsdd_amd import ops
+    tr = dm.transformer
+    B2 = 2 * B
+    st = dm._streams[0]
+    T = dm.num_timesteps
     with torch.cuda.stream(st):
-        dm.transformer.run(tok, condv, Te, t2, ws, rep=rep, stream=st)              # warm
-        ws["attn_events"] = events
+        conds = torch.cat([cond, cf_cond], 0).contiguous()
+        condv = tr.cond_vectors(conds)
+        ws = tr.workspace(B2, L, device, rep=2)
+        tok = torch.randint(0, K, (B, L), device=device)
+        tok[torch.rand((B, L), device=device) < 0.5] = K               # half [MASK], like the middle of a chain
+        t2 = torch.full((B2,), T // 2, dtype=torch.int64, device=device)
+        sid = torch.zeros((1,), dtype=torch.int64, device=device)
+        tok_out = torch.empty_like(tok)
+        M = B * L
+
+        def one():
+            logits = tr.run(tok, condv, 1, t2, ws, rep=2, stream=st)
+            ev = ws.get("events")
+            if ev is not None:
+                ev.setdefault("step", []).append((ops.Event(), ops.Event()))
+                ev["step"][-1][0].record(st)
+            ops.d3pm_step(logits[:M], logits[M:], tok, tok_out, dm._sched(), t2, sid, K=K, T=T, guidance=float(dm.guidance_scale),
+                          seed=1, row0=0, stream=st)
+            if ev is not None:
+                ev["step"][-1][1].record(st)
+
+        one()                                                           # warm
+        events = {}
+        ws["events"] = events
         for _ in range(reps):
-            dm.transformer.run(tok, condv, Te, t2, ws, rep=rep, stream=st)
-        ws.pop("attn_events")
+            one()
+        ws.pop("events")
     st.synchronize()
-    ms = sum(e0.elapsed_ms(e1) for e0, e1 in events) / len(events)
+
+    def mean_ms(name):
+        ev = events[name]
+        return sum(e0.elapsed_ms(e1) for e0, e1 in ev) / len(ev), len(ev)
+
+    pm = P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][0]
+    kernel = f"d3pm_attention_v4_kernel<384, {pm}>"
+    ms, n = mean_ms("attention")
     flops = 16.0 * L * L * H * B2
     tf = flops / (ms * 1e-3) / 1e12
-    traffic = None
-    if (B2, L, H) == (32, 4096, 16):
-        traffic = (2 * 82043.7 + 33846.8) * 1024      # profiles/r2_pmc_traffic.csv, d3pm_attention_v4_kernel<384;8>
-    return {"bound": "mfma", "kernel": f"d3pm_attention_v4_kernel<384, {P_MODES[os.environ.get('GSDD_ATTN_P', 'a8')][0]}>",
-            "achieved": round(tf, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "ms_per_launch": round(ms, 4), "launches_timed": len(events), "flops_per_launch": flops}
+    traffic, src = profile_traffic(kernel) if (B2, L, H) == (32, 4096, 16) else (None, None)
+    roof = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src, "ms_per_launch": round(ms, 4),
+            "launches_timed": n, "flops_per_launch": flops,
+            "timed_as": f"one full batch of {B2} rows on one stream, after the timed region"}
+
+    fam = {}
+    Mrows = B2 * L
+    ms, n = mean_ms("layer")                      # proj + MLP + next q|k|v (blocks 0..n-2: the full chain of four GEMMs)
+    fl = 2.0 * (64 * 64 + 2 * 64 * 256 + 64 * 192) * Mrows
+    fam["gemm_family_fused_layer"] = {"bound": "mfma", "kernel": "d3pm_layer_h2_kernel<true, false>", "ms_per_launch": round(ms, 4),
+                                      "launches_timed": n, "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+    ms, n = mean_ms("logits")
+    fl = 2.0 * 64 * K * Mrows
+    fam["logits"] = {"bound": "mfma", "kernel": "d3pm_logits_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
+                     "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "hbm_write_GBs": round(Mrows * K * 4.0 / ms / 1e6, 1), "hbm_frac": round(Mrows * K * 4.0 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    ms, n = mean_ms("step")
+    by = 2.0 * M * K * 4
+    fam["posterior_step"] = {"bound": "hbm", "kernel": "d3pm_step_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
+                             "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    # decode: the whole VQ-VAE decoder (implicit-GEMM convs), 221.0 GFLOP per 16x128x128 clip (SURVEY.md section 8(d))
+    codes = torch.randint(0, K, (B,) + tuple(grid), device=device)
+    vq.decode(codes)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        vq.decode(codes)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    if tuple(grid) == (16, 16, 16):
+        fl = 221.0e9 * B
+        fam["decode"] = {"bound": "mfma", "kernel": "gemm_kernel (VQ-VAE decoder, all launches)", "ms_per_call": round(ms, 3),
+                         "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+    return roof, fam
 
 
 def cpu_baseline(args, dm, vq, L):
-    """The CPU oracle (our restatement of the reference path, torch-CPU ops) on a bounded sample:
-    one guided reverse step at B=1 (2 denoiser passes + posterior + Gumbel) and one decode, extrapolated
-    to a whole video = diffusion_steps reverse steps + 1 decode."""
+    """The CPU oracle (our restatement of the reference path, torch-CPU ops) on a bounded sample of the same workload, as SURVEY.md
+    section 8(d) prescribes: 3 guided reverse steps at B=1 (2 denoiser passes + posterior + Gumbel each) extrapolated x T/3, plus
+    one decode; next to it the reference's shipped-default length L=1024 (same weights, position table cut to 1024)."""
     from oracle import d3pm as od, vqvae as ov
     sd = {k: v.detach().cpu() for k, v in dm.state_dict().items()}
     vsd = {k: v.detach().cpu() for k, v in vq.state_dict().items()}
@@ -96,22 +171,33 @@ def cpu_baseline(args, dm, vq, L):
     K = args.codes
     T = args.diffusion_steps
     g = torch.Generator().manual_seed(1)
-    tok = torch.randint(0, K, (1, L), generator=g)
-    tok[torch.rand(1, L, generator=g) < 0.5] = K
-    cond = torch.randn(1, 1, 512, generator=g)
-    t = torch.full((1,), T // 2, dtype=torch.long)
-    with torch.no_grad():
+
+    def steps(Lx, n):
+        tok = torch.randint(0, K, (1, Lx), generator=g)
+        tok[torch.rand(1, Lx, generator=g) < 0.5] = K
+        cond = torch.randn(1, 1, 512, generator=g)
         t0 = time.perf_counter()
-        od.p_sample_step(tok, cond, torch.zeros_like(cond), t, sd, 2.0, None, 0)
-        t_step = time.perf_counter() - t0
+        for i in range(n):
+            t = torch.full((1,), T // 2 - i, dtype=torch.long)
+            tok, _ = od.p_sample_step(tok, cond, torch.zeros_like(cond), t, sd, 2.0, None, i)
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        n = 3
+        t_step = steps(L, n)
         codes = torch.randint(0, K, (1,) + tuple(args.grid), generator=g)
         t0 = time.perf_counter()
         ov.decode(codes, vsd, cfg)
         t_dec = time.perf_counter() - t0
+        t_1024 = steps(1024, n) if L > 1024 else None
     per_video = T * t_step + t_dec
-    return {"value": 1.0 / per_video, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 guided reverse step at B=1 L={L} ({t_step:.2f} s) x{T} + 1 decode ({t_dec:.2f} s), "
-                      "torch-CPU oracle"}
+    out = {"value": 1.0 / per_video, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} guided reverse steps at B=1 L={L} ({t_step:.2f} s each) x{T}/{n} + 1 decode ({t_dec:.2f} s), "
+                     "torch-CPU oracle"}
+    if t_1024 is not None:
+        out["shipped_default_L1024"] = {"value": 1.0 / (T * t_1024 + t_dec), "unit": "videos/s",
+                                        "sample": f"{n} guided reverse steps at B=1 L=1024 ({t_1024:.2f} s each) x{T}/{n} + the same decode"}
+    return out
 
 
 LAYER_ARITH = {
@@ -150,7 +236,8 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches of the sampler (separate HIP streams)")
+    ap.add_argument("--lanes", type=int, default=2, help="concurrent sub-batches of the sampler on separate HIP streams (the sampler's "
+                                                        "default: two when the batch allows it; tokens do not depend on it)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side regimes (trained-like weights, zero cond)")
     args = ap.parse_args()
 
@@ -183,8 +270,11 @@ def main():
     dm.set_noise(1234, 0, row_offset=rank * B)
     dm.sample_lanes = args.lanes
 
+    dm_last_tokens = [None]
+
     def one_pass():
         out = dm.sample(texts, None, cond, cf_cond, content_token=None, filter_ratio=0, use_graph=not args.no_graph)
+        dm_last_tokens[0] = out["content_token"]
         clips = vq.decode(out["content_token"].view(B, *args.grid))
         return clips
 
@@ -197,16 +287,17 @@ def main():
     for _ in range(args.warmup):
         clips = one_pass()
     barrier()
-    from gsdd_amd import ops as _ops
-    _ops.d3pm_attention_redo_count(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         clips = one_pass()
     barrier()
     dt = time.perf_counter() - t0
-    headline_redo = _ops.d3pm_attention_redo_count(reset=True) / max(args.steps, 1)
+    headline_redo = dm.attention_redo_events()                     # of the last timed pass (device counters of its workspaces)
+    lanes_used = dm._last_lanes
+    tok = dm_last_tokens[0]
     assert tuple(clips.shape) == (B, 3, args.grid[0], args.grid[1] * 8, args.grid[2] * 8)
     assert torch.isfinite(clips).all()
+    assert tok.dtype == torch.int64 and int(tok.min()) >= 0 and int(tok.max()) < args.codes, "a [MASK] or out-of-range token survived"
     rank_s = [dt]
     if world > 1:
         import torch.distributed as dist
@@ -228,7 +319,7 @@ def main():
                                    f"{args.layers} layers, bs {B}/GPU + VQ-VAE decode to 3x{args.grid[0]}x"
                                    f"{args.grid[1] * 8}x{args.grid[2] * 8}",
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
-                       "hipgraph": not args.no_graph,
+                       "hipgraph": not args.no_graph, "sampler_lanes": lanes_used,
                        "arith": "f32 results; QK^T, to_logits and VQ-VAE GEMM operands as error-free 3-way bf16 splits on the matrix "
                                 "pipe (dropped terms < 2^-24); " + LAYER_ARITH[os.environ.get("GSDD_LAYER", "h2")] +
                                 "; softmax P: " + P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][1]},
@@ -237,9 +328,9 @@ def main():
         }
         # the two side measurements must never cost the run its JSON line
         try:
-            line["roofline"] = attention_roofline(dm, B, L, 16, device, args.codes)
+            line["roofline"], families = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid)
         except Exception as e:                                   # noqa: BLE001
-            line["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+            line["roofline"], families = {"error": f"{type(e).__name__}: {e}"}, None
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, dm, vq, L)
@@ -247,33 +338,35 @@ def main():
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra:
             # regimes the dominant kernel could be sensitive to, outside the timed headline (same process, one warm + one timed
-            # pass each): the reference-faithful zero conditioning, and weights of a trained-like magnitude (peaky softmax rows);
-            # redo_chunks = overflow-redo events of the attention kernel per timed pass
+            # pass each): the reference-faithful zero conditioning, one lane instead of two, and weights of a trained-like
+            # magnitude (peaky softmax rows); redo_chunks = overflow-redo events of the attention kernel per timed pass
             try:
-                from gsdd_amd import ops
-
                 def timed(cond_):
                     nonlocal cond
                     keep, cond = cond, cond_
                     one_pass()
                     torch.cuda.synchronize()
-                    ops.d3pm_attention_redo_count(reset=True)
                     t1 = time.perf_counter()
                     one_pass()
                     torch.cuda.synchronize()
                     d = time.perf_counter() - t1
                     cond = keep
-                    return round(B / d, 4), ops.d3pm_attention_redo_count(reset=True)
-                extra = {}
+                    return round(B / d, 4), dm.attention_redo_events()
+                extra = {"unit": "videos/s", "redo_chunks_headline": headline_redo}
+                if families is not None:
+                    extra["roofline_families"] = families
                 extra["zero_cond"], extra["redo_chunks_zero_cond"] = timed(torch.zeros_like(cond))
-                if args.lanes == 1 and B % 2 == 0 and B // 2 >= 4:
-                    dm.sample_lanes = 2                        # two half-batches on two HIP streams (same tokens: the noise key is the
-                    extra["two_lanes"], _ = timed(cond)        # global row); not the headline: per-launch timing wants one lane
-                    dm.sample_lanes = 1
+                other = 1 if lanes_used > 1 else 2
+                dm.sample_lanes = other                        # same tokens either way: the noise key is the global row
+                extra["one_lane" if other == 1 else "two_lanes"], _ = timed(cond)
+                dm.sample_lanes = args.lanes
                 trained_like_weights(dm)
                 extra["trained_like"], extra["redo_chunks_trained_like"] = timed(cond)
-                extra["unit"] = "videos/s"
-                extra["redo_chunks_headline"] = headline_redo
+                try:
+                    roof_t, _ = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid, reps=1)
+                    extra["trained_like_attention_ms_per_launch"] = roof_t["ms_per_launch"]
+                except Exception:                                # noqa: BLE001
+                    pass
                 line["extra"] = extra
             except Exception as e:                               # noqa: BLE001
                 line["extra"] = {"error": f"{type(e).__name__}: {e}"}

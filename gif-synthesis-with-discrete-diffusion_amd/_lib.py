@@ -15,7 +15,7 @@ EXPORTS = [
     "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
     "gsdd_codebook_ema", "gsdd_code_perplexity", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
-    "gsdd_d3pm_attention", "gsdd_d3pm_attention_redo_count", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_layer_pack", "gsdd_d3pm_layer_pack_h2", "gsdd_rows_linear_pack_many", "gsdd_rows_linear", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_gelu2", "gsdd_ln_fwd", "gsdd_ln_bwd", "gsdd_wgrad",
+    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_layer_pack", "gsdd_d3pm_layer_pack_h2", "gsdd_rows_linear_pack_many", "gsdd_rows_linear", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_gelu2", "gsdd_ln_fwd", "gsdd_ln_bwd", "gsdd_wgrad",
     "gsdd_batch_rowsum", "gsdd_colsum", "gsdd_d3pm_attention_train", "gsdd_d3pm_attention_bwd", "gsdd_d3pm_attention_bwd_workspace_bytes", "gsdd_d3pm_embed_bwd", "gsdd_small_linear_bwd",
     "gsdd_adaln_bwd", "gsdd_adam", "gsdd_adam_multi", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
@@ -65,7 +65,7 @@ class LayerDesc(C.Structure):
         ("y", _p), ("x", _p), ("M", _i64), ("L", _i), ("n_embd", _i), ("hidden", _i), ("cvec", _p),
         ("wproj", _p), ("bproj", _p), ("ln2_g", _p), ("ln2_b", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p),
         ("ada", _p), ("t2", _p), ("wqkv", _p), ("bqkv", _p), ("qkv", _p), ("w2_x3", _p), ("wqkv_x3", _p), ("kv_img", _p),
-        ("layer_h2", _p), ("wqkv_h2", _p),
+        ("layer_h2", _p), ("wqkv_h2", _p), ("range_flag", _p),
     ]
 
 
@@ -104,8 +104,7 @@ def lib():
         L.gsdd_d3pm_embed.argtypes = [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p]
         L.gsdd_adaln_table.argtypes = [_p, _i, _i, _p, _p, _p, _p]
         L.gsdd_small_linear.argtypes = [_p, _i, _i, _p, _p, _i, _p, _p]
-        L.gsdd_d3pm_attention.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _p]
-        L.gsdd_d3pm_attention_redo_count.argtypes = [C.POINTER(C.c_uint64), _i]
+        L.gsdd_d3pm_attention.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _p, _p]
         L.gsdd_d3pm_attention_workspace_bytes.argtypes = [_i, _i, _i]
         L.gsdd_d3pm_attention_workspace_bytes.restype = _i64
         L.gsdd_d3pm_layer.argtypes = [C.POINTER(LayerDesc), _p]

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
 
 #include "../../include/gsdd.h"
@@ -29,6 +30,16 @@ void set_error(const std::string& s);
     } while (0)
 
 #define GSDD_CHECK_LAUNCH() GSDD_CHECK_HIP(hipGetLastError())
+
+// true the first time a call site runs on the current device (hipFuncSetAttribute for dynamic LDS is per device)
+inline bool first_on_device(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
 
 constexpr int WAVE = 64;
 
@@ -130,6 +141,51 @@ __device__ __forceinline__ void kv_image_store_v(const float (&vs)[4], int64_t r
     _Float16* dst = reinterpret_cast<_Float16*>(vp + (pair * 4 + g) * 16) + 4 * th + r;
 #pragma unroll
     for (int j = 0; j < 16; ++j) dst[j * 8] = col[j];
+}
+
+// Per-tile key norms of the attention workspace: knorm[(h*M + b*L + key) >> 5] = an upper bound of max ||k|| over the 32 keys of
+// that pair-tile (f32, rounded up).  With the wave's ||q|| it bounds every score of a (query, pair-tile) by Cauchy-Schwarz, which is
+// how the attention kernel proves "no probability of this tile can matter" without looking at the scores (d3pm_attention.hip).
+// Workspace layout (gsdd_d3pm_attention_workspace_bytes): K image 32 B per (key, head) | V image 32 B | knorm 4 B per 32 keys.
+__host__ __device__ __forceinline__ float* kv_image_knorm(void* workspace, int64_t rows) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + rows * 64);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_min(float v) {
+    return fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+}
+// maximum of a non-negative value over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15): xor 1, xor 2, half mirror, mirror
+__device__ __forceinline__ float row16_max(float v) {
+    v = dpp_max<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_max<0x141>(v);       // row_half_mirror
+    return dpp_max<0x140>(v);    // row_mirror
+}
+__device__ __forceinline__ float row16_min(float v) {
+    v = dpp_min<0xB1>(v);
+    v = dpp_min<0x4E>(v);
+    v = dpp_min<0x141>(v);
+    return dpp_min<0x140>(v);
+}
+// ||k|| bound of one pair-tile from per-lane squared norms: lanes of a 32-lane half hold the 32 keys; lane 0 of the half gets it
+__device__ __forceinline__ float half32_norm_bound(float n2) {
+    float v = row16_max(n2);
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return sqrtf(v) * 1.000001f + 1e-30f;
+}
+// fused layer kernels: lane (li = row of the 32-row group, h) holds k of heads 8 (q >> 2) + 2 (q & 3) + h in o[q]
+__device__ __forceinline__ void kv_image_store_knorm(const float4 (&o)[8], int h, int li, int64_t grp, int64_t M, float* knorm) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float n2 = (o[q].x * o[q].x + o[q].y * o[q].y) + (o[q].z * o[q].z + o[q].w * o[q].w);
+        const float nb = half32_norm_bound(n2);
+        const int hd = 8 * (q >> 2) + 2 * (q & 3) + h;
+        if (li == 0) knorm[(int64_t)hd * (M >> 5) + grp] = nb;
+    }
 }
 
 // axial_attention_mfma.hip: register-resident MFMA kernels for 16-position lines; false = shape not covered

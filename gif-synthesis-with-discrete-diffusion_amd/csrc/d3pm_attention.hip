@@ -371,23 +371,31 @@ __device__ __forceinline__ bool any_gt_h8(const uint4& hi, uint32_t thr2) {
 //   Vp[row/32][4][16] uint4 : per 32-key pair-tile, [key group g][col j] -> 8 f16 (tile0 keys 4g+r, tile1 keys 4g+r),
 //                             cols = [v1 | v2*2^11 | v3*2^22 | 1 | 0 0 0]
 __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                             int64_t rows, uint4* __restrict__ kp, uint4* __restrict__ vp) {
+                                                             int64_t rows, uint4* __restrict__ kp, uint4* __restrict__ vp,
+                                                             float* __restrict__ knorm) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;       // row = h*M + b*L + key (L % 32 == 0)
-    if (row >= rows) return;
+    if (row >= rows) return;                                          // rows % 32 == 0: whole 32-lane halves leave together
     const float4 rk = *reinterpret_cast<const float4*>(k + row * 4);
     const float4 rv = *reinterpret_cast<const float4*>(v + row * 4);
     const float ks[4] = {rk.x, rk.y, rk.z, rk.w}, vs[4] = {rv.x, rv.y, rv.z, rv.w};
     kv_image_store_k(ks, row, kp);
     kv_image_store_v(vs, row, vp);
+    const float nb = half32_norm_bound((rk.x * rk.x + rk.y * rk.y) + (rk.z * rk.z + rk.w * rk.w));
+    if ((threadIdx.x & 31) == 0) knorm[row >> 5] = nb;
 }
 
 // One pass over the pair-tiles of a staged chunk for the wave's 4 x 16 queries.  MODE 1: P = hi + lo; 0: hi only; 2: hi, and lo only
 // where a tile holds a probability above the lane's threshold thr2 (see the kernel's note) -- returns the number of (pair-tile,
 // query sub-tile) pairs that skipped the lo half.  (Deciding once per pair-tile for the four sub-tiles together, with the rare path
 // recomputing the scores, measured 3 % faster on flat rows and 7 % slower on trained-like ones: not kept.)
+//
+// MODE 2 asks the *bound* first: bit u of skipmask[j] (scalar registers) says that no probability of pair-tile u can exceed 2^-PM of
+// any row sum of query sub-tile j -- proven from ||q|| ||k|| (kernel note), so the tile takes the hi half only and nothing is
+// measured.  Where the bound does not decide, `measure` (wave-uniform) selects the measured test above or hi + lo outright.
 template <int KC4, int MODE>
 __device__ __forceinline__ int attn_tiles(const AttnSmem4<KC4>& sm, int buf, int npairs, const uint4* kb, int kstep, int lg, int li,
-                                          const uint4 (&qfrag)[4], f32x4 (&acc)[4], const uint32_t (&thr2)[4]) {
+                                          const uint4 (&qfrag)[4], f32x4 (&acc)[4], const uint32_t (&thr2)[4],
+                                          const uint32_t (&skipmask)[4], bool measure) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int skipped = 0;
     for (int u = 0; u < npairs; ++u) {
@@ -410,11 +418,13 @@ __device__ __forceinline__ int attn_tiles(const AttnSmem4<KC4>& sm, int buf, int
                 round_p8(p, hi);
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(hi), vb, acc[j], 0, 0, 0);
                 if (MODE == 2) {
-                    if (__any(any_gt_h8(hi, thr2[j]))) {             // wave-uniform: some probability of this tile matters
-                        resid_p8(p, hi, lo);
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
-                    } else {
-                        ++skipped;
+                    if (!((skipmask[j] >> u) & 1u)) {                     // scalar test: the bound did not clear this tile
+                        if (!measure || __any(any_gt_h8(hi, thr2[j]))) { // wave-uniform: some probability of this tile matters
+                            resid_p8(p, hi, lo);
+                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(lo), vb, acc[j], 0, 0, 0);
+                        } else {
+                            ++skipped;
+                        }
                     }
                 }
             }
@@ -423,9 +433,8 @@ __device__ __forceinline__ int attn_tiles(const AttnSmem4<KC4>& sm, int buf, int
     return skipped;
 }
 
-// Diagnostic: how often the rare "accumulator overflowed, redo this chunk with a larger exponent offset" branch ran (one count per
-// workgroup and redo attempt).  The kernel's cost depends on the data through that branch only; bench.py reports the count per pass.
-__device__ unsigned long long g_attn_redo_events = 0ull;
+// Diagnostic (`redo`, optional caller-owned device counter): how often the rare "accumulator overflowed, redo this chunk with a larger
+// exponent offset" branch ran (one count per wave and redo attempt); bench.py reports the count per pass.
 
 // PM selects how the probabilities reach the P.V product:
 //   PM = 1   P = hi + lo (22 bits) everywhere: the parity default.
@@ -434,11 +443,22 @@ __device__ unsigned long long g_attn_redo_events = 0ull;
 //            query's row sum so far.  A probability below that carries a rounding error below 2^-(12+PM) of the row sum; the
 //            errors of the skipped tiles add up (randomly signed) to at most 2^-(PM/2) * 2^-12 / sqrt(3) of |v - o|.  With flat
 //            rows everything after the first few hundred keys is "small"; with peaky rows only the tiles holding a peak pay.
+//            Whether a tile can hold such a probability is first asked of a BOUND, not of the scores: every score of query q
+//            against pair-tile u is at most ||q'|| * knorm[u] (Cauchy-Schwarz; q' = q scaled into the log2 domain, knorm = the
+//            tile's largest ||k||, written next to the K image by whoever made it), so all its probabilities 2^(s - m) stay below
+//            2^-PM * (row sum at the start of the chunk) whenever
+//                knorm[u] < (log2(row sum) - PM + m - slack) / ||q'||          (the right side: one number per query and chunk).
+//            The minimum of that number over the 16 queries of a sub-tile is compared with the chunk's 12 tile norms in one
+//            v_cmp; the resulting mask lives in a scalar register and the tile loop tests a bit of it -- no per-score vector work.
+//            A chunk whose tiles are all cleared runs the hi-only loop (flat rows: every chunk after the first); tiles the bound
+//            cannot clear fall back to the measured test (two v_pk_maximum3_f16 on the rounded probabilities) or to hi + lo.
+//            The bound only ever clears tiles the measured test would have cleared too, so the error budget above is unchanged.
 // The error each mode costs is measured by tools/attn_error.py and tabled in DESIGN.md.
 template <int KC4, int PM = 1>
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
-                                                                const uint4* __restrict__ vp, int B, int L, int H,
-                                                                float* __restrict__ out, float* __restrict__ lse) {
+                                                                const uint4* __restrict__ vp, const float* __restrict__ knorm,
+                                                                int B, int L, int H, float* __restrict__ out,
+                                                                float* __restrict__ lse, unsigned long long* __restrict__ redo) {
     __shared__ AttnSmem4<KC4> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqb = (L + 255) / 256;
@@ -455,6 +475,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     const float* qh = q + base;
     const uint4* kph = kp + ((int64_t)h * M + (int64_t)b * L) * 2;        // 2 uint4 per key
     const uint4* vph = vp + (((int64_t)h * M + (int64_t)b * L) >> 5) * 64; // 64 uint4 per 32-key pair-tile
+    const float* knh = knorm + (((int64_t)h * M + (int64_t)b * L) >> 5);   // one float per 32-key pair-tile
     const int li = lane & 15, lg = lane >> 4;
     const int q0 = qblk * 256 + wave * 64;
 
@@ -462,6 +483,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
 
     const float qscale = 0.5f * 1.4426950408889634f;
     uint4 qfrag[4];
+    float rqn[4];                               // PM >= 2: 1 / (||q'|| of query li, rounded up): the score bound's slope
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int qi = q0 + 16 * j + li;
@@ -473,11 +495,14 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         for (int d = 0; d < 4; ++d) split3(qs[d], q1[d], q2[d], q3[d]);
         const uint4 f0 = pack8(q1, q1), f1 = pack8(q2, q2), f2 = pack8(q1, q3);
         qfrag[j] = lg == 0 ? f0 : (lg == 1 ? f1 : (lg == 2 ? f2 : make_uint4(0u, 0u, 0u, 0u)));
+        // 1.0001: the split products, the norms' own rounding and v_rcp/v_log/v_sqrt (1 ulp each) are all below 2^-20 relative
+        rqn[j] = 1.0f / (sqrtf((qs[0] * qs[0] + qs[1] * qs[1]) + (qs[2] * qs[2] + qs[3] * qs[3])) * 1.0001f + 1e-30f);
     }
 
     const int nchunks = (L + KC4 - 1) / KC4;
     // chunk staging = plain copy of the pre-split images: K 768 uint4 + V 768 uint4 per 384-key chunk
     uint4 rk0, rk1, rk2, rv0, rv1, rv2;
+    float rkn = 0.f, kn_cur = 0.f;              // PM >= 2: lane u < KC4 / 32 holds the norm bound of pair-tile u of the chunk
     auto load_chunk = [&](int c) {
         // Unconditional loads from a clamped index: a load under "cond ? p[i] : zero" becomes a *flat* load from either the
         // image or a scratch copy of the zero, and flat loads also count on lgkmcnt, so the first LDS fragment wait of the chunk
@@ -487,12 +512,14 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         const uint4* vsrc = vph + (int64_t)c * (KC4 / 32) * 64;
         rk0 = ksrc[min(tid, last)]; rk1 = ksrc[min(tid + 256, last)]; rk2 = ksrc[min(tid + 512, last)];
         rv0 = vsrc[min(tid, last)]; rv1 = vsrc[min(tid + 256, last)]; rv2 = vsrc[min(tid + 512, last)];
+        if (PM >= 2) rkn = knh[min(c * (KC4 / 32) + min(lane, KC4 / 32 - 1), (L >> 5) - 1)];
     };
     auto store_chunk = [&](int buf, int) {
         uint4* kd = &sm.k[buf][0][0];
         uint4* vd = &sm.v[buf][0][0][0];
         kd[tid] = rk0; kd[tid + 256] = rk1; kd[tid + 512] = rk2;
         vd[tid] = rv0; vd[tid + 256] = rv1; vd[tid + 512] = rv2;
+        kn_cur = rkn;
     };
 
     f32x4 acc[4], sav[4];
@@ -549,26 +576,46 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         for (int attempt = prescan ? -1 : 0; attempt < 16; ++attempt) {
           if (attempt >= 0) {
             uint32_t thr2[4] = {0u, 0u, 0u, 0u};
-            if (PM >= 2 && adapt) {
-                // threshold of query li = 2^-PM * its row sum at the start of this chunk (accumulator column 12, row li: lane
-                // 16 (li >> 2) + 12, register li & 3), as an f16 replicated in both halves.  A zero row sum (first chunk) makes every
-                // tile take the lo half; an inf threshold (row sum beyond the f16 range) none -- both are what the bound wants.
+            uint32_t skipmask[4] = {0u, 0u, 0u, 0u};
+            if (PM >= 2 && c > 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    // row sum of query li at the start of this chunk: accumulator column 12, row li = lane 16 (li >> 2) + 12, register li & 3
                     const int src = ((li >> 2) << 4) + 12;
                     const float r0 = __shfl(sav[j][0], src), r1 = __shfl(sav[j][1], src), r2 = __shfl(sav[j][2], src),
                                 r3 = __shfl(sav[j][3], src);
                     const int rr = li & 3;
                     const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
-                    const _Float16 th = (_Float16)(rs * (1.0f / (float)(1 << PM)));
-                    const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, th);
-                    thr2[j] = hb | (hb << 16);
+                    // the bound (kernel note): per query the largest tile norm that still keeps every probability below 2^-PM of the
+                    // row sum; its minimum over the sub-tile's 16 queries (a DPP row) against the tile norms held by lanes 0..11.
+                    // 0.02 of slack in the exponent: v_log_f32 is good to 1 ulp of a value below 2^5 here.  A zero row sum gives
+                    // -inf, a NaN one NaN: fmaxf turns both into 0, "never cleared".
+                    float kbq = (__builtin_amdgcn_logf(rs) - (float)PM + mq[j] - 0.02f) * rqn[j];
+                    kbq = fmaxf(kbq, 0.f);
+                    const float kbj = row16_min(kbq);
+                    skipmask[j] = (uint32_t)__ballot(kn_cur < kbj);
+                    if (adapt) {
+                        // measured test: threshold of query li = 2^-PM * that row sum, as an f16 replicated in both halves.  A zero
+                        // row sum makes every tile take the lo half; an inf threshold (row sum beyond the f16 range) none.
+                        const _Float16 th = (_Float16)(rs * (1.0f / (float)(1 << PM)));
+                        const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, th);
+                        thr2[j] = hb | (hb << 16);
+                    }
                 }
             }
+            const uint32_t allmask = (1u << npairs) - 1u;
+            const uint32_t clr_all = skipmask[0] & skipmask[1] & skipmask[2] & skipmask[3] & allmask;
+            const uint32_t clr_any = (skipmask[0] | skipmask[1] | skipmask[2] | skipmask[3]) & allmask;
             int skipped = 0;
-            if (PM == 0) attn_tiles<KC4, 0>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2);
-            else if (PM == 1 || !adapt) attn_tiles<KC4, 1>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2);
-            else skipped = attn_tiles<KC4, 2>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2);
+            const bool cleared = PM >= 2 && clr_all == allmask;          // every tile of the chunk, for all 64 queries
+            if (PM == 0 || cleared) attn_tiles<KC4, 0>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2, skipmask, false);
+            else if (PM == 1 || (!adapt && clr_any == 0u))
+                attn_tiles<KC4, 1>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2, skipmask, false);
+            else {
+                skipped = attn_tiles<KC4, 2>(sm, buf, npairs, kb, kstep, lg, li, qfrag, acc, thr2, skipmask, adapt);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) skipped += __builtin_popcount(skipmask[j] & allmask);
+            }
             // overflow screen (f16 hi part saturated to inf somewhere in this chunk): rare
             // (inf and NaN survive additions, and full-rate adds are cheaper than sixteen half-rate compares)
             float chk = 0.f;
@@ -576,7 +623,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
             for (int j = 0; j < 4; ++j) chk += (acc[j][0] + acc[j][1]) + (acc[j][2] + acc[j][3]);
             const bool bad = !(fabsf(chk) < 3.0e38f);
             if (!__any(bad)) {
-                if (PM >= 2) {
+                if (PM >= 2 && !cleared) {                               // (a cleared chunk says nothing about the measured test)
                     if (adapt) {
                         if (2 * skipped < 4 * npairs) { adapt = false; probe = backoff; backoff *= 2; }
                     } else if (--probe <= 0) {
@@ -586,7 +633,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
                 break;
             }
             moved = true;
-            if (lane == 0) atomicAdd(&g_attn_redo_events, 1ull);
+            if (lane == 0 && redo != nullptr) atomicAdd(redo, 1ull);
           }
             // exact maximum of this chunk's scores per query (relative to the current m), then move m so that the chunk maximum lands
             // in (2^2, 2^3]; accumulators restart from the chunk-start copy scaled by 2^-delta.  After an overflow only the queries
@@ -691,14 +738,15 @@ static int attn_p_mode(int L) {
 }
 
 extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
-    return (int64_t)B * L * H * 64;          // 32 B (K pieces) + 32 B (V image) per key and head
+    const int64_t rows = (int64_t)B * L * H;
+    return rows * 64 + ((rows + 31) / 32) * 4;   // 32 B (K pieces) + 32 B (V image) per key and head, one norm bound per 32 keys
 }
 
 int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
                         void* stream);                                                              // d3pm_bwd.hip
 
 extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
-                                   void* workspace, int64_t workspace_bytes, void* stream) {
+                                   void* workspace, int64_t workspace_bytes, uint64_t* redo_events, void* stream) {
     GSDD_CHECK_ARG(q && out && ((k == nullptr) == (v == nullptr)), "null pointer");
     GSDD_CHECK_ARG(B > 0 && H > 0 && L > 0, "bad sizes");
     GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
@@ -714,33 +762,24 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
         const int64_t rows = (int64_t)B * L * H;
         uint4* kp = reinterpret_cast<uint4*>(workspace);
         uint4* vp = kp + rows * 2;
+        float* kn = kv_image_knorm(workspace, rows);
+        unsigned long long* redo = reinterpret_cast<unsigned long long*>(redo_events);
         if (!premade) {
-            hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
+            hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn);
             GSDD_CHECK_LAUNCH();
         }
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
         const int pmode = attn_p_mode(L);
-        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
-        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
-        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
-        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
-        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, B, L, H, out, (float*)nullptr);
+        float* nolse = nullptr;
+        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
     } else {
-        hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);
+        hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);      // (never redoes a chunk)
     }
     GSDD_CHECK_LAUNCH();
-    return GSDD_OK;
-}
-
-extern "C" int gsdd_d3pm_attention_redo_count(uint64_t* count, int reset) {
-    GSDD_CHECK_ARG(count != nullptr, "null pointer");
-    unsigned long long v = 0ull;
-    GSDD_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_redo_events), sizeof(v)));      // synchronises with the device
-    *count = (uint64_t)v;
-    if (reset) {
-        const unsigned long long z = 0ull;
-        GSDD_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_redo_events), &z, sizeof(z)));
-    }
     return GSDD_OK;
 }
 
@@ -756,17 +795,19 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     const int64_t rows = (int64_t)B * L * H;
     uint4* kp = reinterpret_cast<uint4*>(workspace);
     uint4* vp = kp + rows * 2;
-    hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp);
+    float* kn = kv_image_knorm(workspace, rows);
+    unsigned long long* noredo = nullptr;
+    hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn);
     GSDD_CHECK_LAUNCH();
     // GSDD_ATTN_TRAIN_P=a8 lets the training forward use the sampler's adaptive lo half at L >= 2048 (default: hi + lo everywhere --
     // its output and log-sum-exp feed the backward, where the adaptive mode's extra 1e-5 is noise on gradients that are mathematically zero)
     const char* tp = getenv("GSDD_ATTN_TRAIN_P");
     if (tp != nullptr && tp[0] == 'a' && L >= 2048)
-        hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
-                           out, lse);
+        hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
+                           B, L, H, out, lse, noredo);
     else
-    hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, B, L, H,
-                       out, lse);
+        hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
+                           B, L, H, out, lse, noredo);
     GSDD_CHECK_LAUNCH();
     *done = 1;
     return GSDD_OK;

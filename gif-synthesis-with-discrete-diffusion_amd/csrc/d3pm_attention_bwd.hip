@@ -752,11 +752,10 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     }
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, q, o, dO, lse, im, B, L, H, dqkv);
     GSDD_CHECK_LAUNCH();
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
+    if (first_on_device(attr_done)) {
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(DkvSmem)));
-        attr_done = true;
     }
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), sizeof(DkvSmem), st, k, v, im, B, L, H, dqkv);
     GSDD_CHECK_LAUNCH();

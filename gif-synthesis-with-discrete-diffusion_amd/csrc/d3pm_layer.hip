@@ -44,6 +44,9 @@ struct LayerArgs {
     const uint4* lay_h2;       // optional f16 hi + lo fragment images (gsdd_d3pm_layer_pack_h2)
     const uint4* wqkv_h2;
     uint4* kimg; uint4* vimg;  // optional: the next block's attention images (k, v go there instead of qkv rows)
+    float* knorm;              // with them: per (head, 32-key pair-tile) bound of ||k|| (common.hpp::kv_image_knorm)
+    int* range_flag;           // optional (f16 hi + lo kernel): set to 1 when an updated row of x is not finite, i.e. an activation
+                               // left the f16 operand range somewhere upstream (inf / NaN reach x through the residual adds)
 };
 
 // GELU2 (transformer_utils.py:115-119): v * sigmoid(1.702 v) = v / (1 + 2^(-1.702 log2(e) v)).
@@ -952,6 +955,7 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
                             kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
                         }
                     }
+                    kv_image_store_knorm(o, h, li, grp, a.M, a.knorm);      // M % 32 == 0 here: the group is one whole pair-tile
                 } else if (full) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -1360,6 +1364,15 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_h2_kernel(const LayerArgs a
                 x1[16 * t + r + 2] += fmaf(acc3[t][r + 2], H2_UNSCALE, bb.z);
                 x1[16 * t + r + 3] += fmaf(acc3[t][r + 3], H2_UNSCALE, bb.w);
             }
+        if (a.range_flag != nullptr) {
+            // range screen: operands are 16 a as f16, so |a| >= 4094 (LN output, GELU2 output, attention output) becomes inf,
+            // and inf / NaN then reach this row through the products and the residual adds (a q|k|v-stage overflow: through the
+            // next block's attention).  inf and NaN survive additions, so one sum and one compare per lane test the 32 values.
+            float chk = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) chk += x1[i];
+            if (__any(valid && !(fabsf(chk) < 3.0e38f)) && lane == 0) atomicOr(a.range_flag, 1);
+        }
         if (full) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
@@ -1470,6 +1483,7 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_h2_kernel(const LayerArgs a
                             kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
                         }
                     }
+                    kv_image_store_knorm(o, h, li, grp, a.M, a.knorm);      // M % 32 == 0 here: the group is one whole pair-tile
                 } else if (full) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -1644,16 +1658,16 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     a.wproj = d->wproj; a.bproj = d->bproj; a.ln2_g = d->ln2_g; a.ln2_b = d->ln2_b;
     a.w1 = d->w1; a.b1 = d->b1; a.w2 = d->w2; a.b2 = d->b2;
     a.ada = d->ada; a.t2 = d->t2; a.wqkv = d->wqkv; a.bqkv = d->bqkv; a.qkv = d->qkv;
+    a.range_flag = d->range_flag;
     const size_t lds = (size_t)LDS_LAYER_FLOATS * sizeof(float);
     const int64_t ngroups = (d->M + 31) / 32;
     const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
+    if (first_on_device(attr_done)) {
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
     }
     a.w2_x3 = reinterpret_cast<const uint4*>(d->w2_x3); a.wqkv_x3 = reinterpret_cast<const uint4*>(d->wqkv_x3);
     a.lay_h2 = reinterpret_cast<const uint4*>(d->layer_h2); a.wqkv_h2 = reinterpret_cast<const uint4*>(d->wqkv_h2);
@@ -1664,27 +1678,30 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     const bool have_h2 = (qkv_only || d->layer_h2 != nullptr) && (!has_qkv || d->wqkv_h2 != nullptr);
     int variant;                                               // 0 f32, 1 bf16x3 split on the fly, 2 bf16x3 images, 3 f16 hi + lo images
     if (force == nullptr) variant = have_h2 ? 3 : (have_x3 ? 2 : 1);
-    else if (force[0] == 'f') variant = 0;
-    else if (force[0] == 'h') variant = 3;
-    else variant = force[2] == 'p' ? 2 : 1;
+    else if (strcmp(force, "f32") == 0) variant = 0;
+    else if (strcmp(force, "h2") == 0) variant = 3;
+    else if (strcmp(force, "x3p") == 0) variant = 2;
+    else if (strcmp(force, "x3") == 0) variant = 1;
+    else GSDD_CHECK_ARG(false, "GSDD_LAYER must be one of f32, x3, x3p, h2");
     if (qkv_only && variant < 2) variant = have_h2 ? 3 : 2;
     GSDD_CHECK_ARG(variant != 3 || have_h2, "GSDD_LAYER=h2 needs the gsdd_d3pm_layer_pack_h2 images");
     GSDD_CHECK_ARG(variant != 2 || have_x3, "the bf16x3 image kernel needs the gsdd_d3pm_layer_pack images");
     a.kimg = a.vimg = nullptr;
+    a.knorm = nullptr;
     if (has_qkv && d->kv_img != nullptr) {
         GSDD_CHECK_ARG(variant >= 2 && d->L % 32 == 0, "kv_img needs a packed-weight kernel (fragment images) and L % 32 == 0");
         a.kimg = reinterpret_cast<uint4*>(d->kv_img);
         a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
+        a.knorm = kv_image_knorm(d->kv_img, d->M * 16);
     }
     GSDD_CHECK_ARG(!qkv_only || has_qkv, "y = NULL (q|k|v stage only) needs qkv");
     if (variant == 3) {
         const size_t ldsh = (size_t)H2_LDS_FLOATS * sizeof(float);
-        static bool attr_h = false;
-        if (!attr_h) {
+        static unsigned long long attr_h = 0ull;      // one bit per device: the attribute is per device
+        if (first_on_device(attr_h)) {
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
-            attr_h = true;
         }
         if (qkv_only) hipLaunchKernelGGL((d3pm_layer_h2_kernel<true, true>), dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
         else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_h2_kernel<true>, dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
@@ -1697,12 +1714,11 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
         else hipLaunchKernelGGL(d3pm_layer_x3_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     } else {
         const size_t ldsp = (size_t)X3P_LDS_FLOATS * sizeof(float);
-        static bool attr_p = false;
-        if (!attr_p) {
+        static unsigned long long attr_p = 0ull;      // one bit per device: the attribute is per device
+        if (first_on_device(attr_p)) {
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-            attr_p = true;
         }
         if (qkv_only) hipLaunchKernelGGL((d3pm_layer_x3p_kernel<true, true>), dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
         else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3p_kernel<true>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
@@ -1724,10 +1740,9 @@ extern "C" int gsdd_rows_linear_pack_many(const void* descs_dev, int n_desc, int
 template <int KC, int NB>
 static int rows_linear_launch(const RowsLinArgs& a, void* stream) {
     const size_t ldsb = (size_t)NB * KC * 8 * IMG_FRAG_U4 * 16 + (size_t)64 * NB * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0ull;      // one bit per device: the attribute is per device
+    if (first_on_device(attr)) {
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)rows_linear_kernel<KC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-        attr = true;
     }
     const int64_t ngroups = (a.M + 31) / 32;
     const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
@@ -1782,10 +1797,9 @@ extern "C" int gsdd_d3pm_logits(const float* x, int64_t M, int n_embd, const flo
     LogitsArgs a;
     a.x = x; a.M = M; a.K = K; a.g = ln_g; a.b = ln_b; a.w = w; a.bias = bias; a.out = out;
     const size_t lds = (size_t)2 * LCH * W1P * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
+    if (first_on_device(attr_done)) {
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
     }
     const unsigned grid = (unsigned)std::min<int64_t>((M + 255) / 256, 256);
     hipLaunchKernelGGL(d3pm_logits_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);

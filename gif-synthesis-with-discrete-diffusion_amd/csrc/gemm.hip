@@ -421,11 +421,10 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
         const dim3 grid(gx, (d->Cout + 127) / 128);
         const bool big = x3 && M >= 256 * 1024 / 2 && (int64_t)d->ntaps * d->Cin >= 1024;        // long contraction, many rows
         if (big) {
-            static bool attr_done = false;
-            if (!attr_done) {
+            static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
+            if (first_on_device(attr_done)) {
                 GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<128, true, 256, 512>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GemmSmemX3<128, 256>)));
-                attr_done = true;
             }
             const dim3 grid2((unsigned)((M + 255) / 256), (d->Cout + 127) / 128);
             hipLaunchKernelGGL((gemm_kernel<128, true, 256, 512>), grid2, dim3(512), sizeof(GemmSmemX3<128, 256>), st, *d, M);
@@ -437,11 +436,10 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
         // the matrix-pipe time of the 128 x 64 one on padding columns
         const bool narrow = x3 && d->Cout <= 32 && M >= 256 * 1024 / 2 && (int64_t)d->ntaps * d->Cin >= 1024;
         if (narrow) {
-            static bool attr_done = false;
-            if (!attr_done) {
+            static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
+            if (first_on_device(attr_done)) {
                 GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<32, true, 256, 256>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GemmSmemX3<32, 256>)));
-                attr_done = true;
             }
             const dim3 grid2((unsigned)((M + 255) / 256), 1);
             hipLaunchKernelGGL((gemm_kernel<32, true, 256, 256>), grid2, dim3(256), sizeof(GemmSmemX3<32, 256>), st, *d, M);

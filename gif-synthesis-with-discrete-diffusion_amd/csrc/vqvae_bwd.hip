@@ -496,11 +496,10 @@ extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_
     if (force_f32) {
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), sizeof(CwSmem), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
     } else if (big) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
+        if (first_on_device(attr_done)) {
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sizeof(CwSmemX3<128>)));
-            attr_done = true;
         }
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(512), sizeof(CwSmemX3<128>), (hipStream_t)stream, *d, dY, dy_pitch, dW, M,
                            slabs, ctiles);

@@ -16,6 +16,21 @@ from . import ops
 from ._lib import GsddError
 
 
+@contextlib.contextmanager
+def _timed(ws, name, stream):
+    """bench.py's in-situ timing: with ws["events"] = {} present, a HIP event pair on the launch stream brackets the launches made
+    inside the block and is appended to ws["events"][name]; otherwise (always, in the product path) nothing happens."""
+    ev = ws.get("events") if name is not None else None
+    if ev is None:
+        yield
+        return
+    pair = (ops.Event(), ops.Event())
+    pair[0].record(stream)
+    yield
+    pair[1].record(stream)
+    ev.setdefault(name, []).append(pair)
+
+
 # ----------------------------------------------------------------------------- parameter containers
 class DalleMaskImageEmbedding(nn.Module):
     """dalle_mask_image_embedding.py:27-57 (num_embed+1 rows, last = [MASK])."""
@@ -178,6 +193,30 @@ class Text2ImageTransformer(nn.Module):
             for lay in layers:
                 lay["lay_h2"], lay["wqkv_h2"] = ops.d3pm_layer_pack_h2(lay["w1"], lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
 
+    def demote_to_x3p(self, stream=None):
+        """The f16 hi + lo layer kernel carries activations as 16 a in f16: |a| >= 4094 (an outlier LN / GELU2 / attention output of a
+        trained checkpoint) overflows.  The kernel flags that (LayerDesc.range_flag) and the caller lands here: this weight set takes the
+        bf16x3 kernel, which has f32's range, until the weights change.  -> True if anything changed."""
+        layers = self.packed()["layers"]
+        if not layers or "lay_h2" not in layers[0]:
+            return False
+        for lay in layers:
+            lay.pop("lay_h2", None), lay.pop("wqkv_h2", None)
+            lay["w2_x3"], lay["wqkv_x3"] = ops.d3pm_layer_pack(lay["w2"], lay["wproj"], lay["wqkv"], stream=stream)
+        self.range_demotions = getattr(self, "range_demotions", 0) + 1
+        return True
+
+    def run_checked(self, tok, condv, Te, t2, ws, rep=1, stream=None):
+        """run() + the range screen of the f16 hi + lo layer kernel (one 4-byte read back: eager callers only; sample() checks
+        once per call, after its captured loop)."""
+        logits = self.run(tok, condv, Te, t2, ws, rep=rep, stream=stream)
+        if int(ws["range"].item()) != 0:
+            ws["range"].zero_()
+            if not self.demote_to_x3p(stream):
+                raise GsddError("non-finite activations in the denoiser (inf / NaN in the inputs or weights?)")
+            logits = self.run(tok, condv, Te, t2, ws, rep=rep, stream=stream)
+        return logits
+
     # ------------------------------------------------------------------ one denoiser pass on the HIP path
     def cond_vectors(self, cond):
         """Per-layer cross-attention operands of the condition tokens (B2, Te, cond_dim).
@@ -221,7 +260,7 @@ class Text2ImageTransformer(nn.Module):
                    and not os.environ.get("GSDD_ATTN_V3"))
             x0, q0 = (x[:M1], ws["qkv0"]) if share0 else (x, qkv)
             if img:
-                ops.d3pm_layer(None, x0, L, None, nxt=layers[0], t2=t2, qkv=q0, kv_img=attn_ws, stream=stream)
+                ops.d3pm_layer(None, x0, L, None, nxt=layers[0], t2=t2, qkv=q0, kv_img=attn_ws, range_flag=ws.get("range"), stream=stream)
             else:
                 ops.row_stats(x0, stats, stream=stream)
                 ops.linear(x0, layers[0]["wqkv"], q0, bias=layers[0]["bqkv"],
@@ -230,29 +269,27 @@ class Text2ImageTransformer(nn.Module):
             for li, lay in enumerate(layers):
                 if li == 0 and share0:
                     if img:
-                        ops.d3pm_attention(q0[0:H], None, None, B, L, H, y, ws=attn_ws, stream=stream)
+                        ops.d3pm_attention(q0[0:H], None, None, B, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
                     else:
-                        ops.d3pm_attention(q0[0:H], q0[H:2 * H], q0[2 * H:3 * H], B, L, H, y, ws=attn_ws, stream=stream)
+                        ops.d3pm_attention(q0[0:H], q0[H:2 * H], q0[2 * H:3 * H], B, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
                     with torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else contextlib.nullcontext():
                         for r in range(1, rep):
                             y[r * M1:(r + 1) * M1].copy_(y[:M1])
                 else:
-                    ev = ws.get("attn_events")                 # bench.py: HIP events around the dominant kernel, in situ
-                    if ev is not None:
-                        ev.append((ops.Event(), ops.Event()))
-                        ev[-1][0].record(stream)
-                    if img:
-                        ops.d3pm_attention(qkv[0:H], None, None, B2, L, H, y, ws=attn_ws, stream=stream)
-                    else:
-                        ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=attn_ws, stream=stream)
-                    if ev is not None:
-                        ev[-1][1].record(stream)
+                    with _timed(ws, "attention", stream):      # bench.py: HIP events around the dominant kernel, in situ
+                        if img:
+                            ops.d3pm_attention(qkv[0:H], None, None, B2, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
+                        else:
+                            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
                 nxt = layers[li + 1] if li + 1 < len(layers) else None
-                ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, kv_img=attn_ws if img else None, stream=stream)
+                with _timed(ws, "layer" if nxt is not None else None, stream):
+                    ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, kv_img=attn_ws if img else None,
+                                   range_flag=ws.get("range"), stream=stream)
         else:
             self._run_blocks_unfused(layers, condv, Te, t2, ws, B2, L, stream)
         if D == 64 and p["wl"].shape[0] % 4 == 0:
-            ops.d3pm_logits(x, p["gf"], p["bf"], p["wl"], p["bl"], logits, stream=stream)
+            with _timed(ws, "logits", stream):
+                ops.d3pm_logits(x, p["gf"], p["bf"], p["wl"], p["bl"], logits, stream=stream)
         else:
             ops.row_stats(x, stats, stream=stream)
             ops.linear(x, p["wl"], logits, bias=p["bl"], ln=(stats, p["gf"], p["bf"], None, 0), stream=stream)
@@ -267,7 +304,7 @@ class Text2ImageTransformer(nn.Module):
             ops.linear(x, lay["wqkv"], qkv, bias=lay["bqkv"],
                        ln=(stats, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t2, 2 * D),
                        rows_per_batch=L, out_mode=2, stream=stream)
-            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), stream=stream)
+            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), redo=ws.get("redo"), stream=stream)
             if Te == 1:
                 ops.linear(y, lay["wproj"], x, bias=lay["bproj"], bvec=condv[li], rows_per_batch=L, residual=x,
                            stream=stream)
@@ -293,7 +330,11 @@ class Text2ImageTransformer(nn.Module):
         ws = {"x": torch.empty((M, D), **f), "stats": torch.empty((M, 2), **f),
               "qkv": torch.empty((3 * H, M, 4), **f), "y": torch.empty((M, D), **f),
               "h": torch.empty((M, self.blocks[0].mlp[0].out_features), **f),
-              "logits": torch.empty((M, K), **f), "attn": ops.d3pm_attention_workspace(B2, L, H, device)}
+              "logits": torch.empty((M, K), **f), "attn": ops.d3pm_attention_workspace(B2, L, H, device),
+              # chunk-redo events of the attention kernel since this workspace was made (a device counter the caller owns)
+              "redo": torch.zeros((1,), dtype=torch.int64, device=device),
+              # set by the f16 hi + lo layer kernel when an activation left its operand range (checked by the callers of run())
+              "range": torch.zeros((1,), dtype=torch.int32, device=device)}
         if rep > 1:                                  # block 0's q|k|v of one copy (the copies share it, see run())
             ws["qkv0"] = torch.empty((3 * H, M // rep, 4), **f)
         return ws
@@ -308,7 +349,7 @@ class Text2ImageTransformer(nn.Module):
         ws = self.workspace(B, L, input.device)
         cond_emb = cond_emb.float()
         condv = self.cond_vectors(cond_emb)
-        logits = self.run(input.contiguous(), condv, cond_emb.shape[1], t.to(input.device).long().contiguous(), ws)
+        logits = self.run_checked(input.contiguous(), condv, cond_emb.shape[1], t.to(input.device).long().contiguous(), ws)
         return logits.view(B, L, -1).transpose(1, 2)
 
 
@@ -373,7 +414,8 @@ class DiffusionTransformer(nn.Module):
         self.noise_seed = 0          # Philox key; the stream id advances with every draw
         self.noise_stream = 0
         self.row_offset = 0          # global row of this rank's first sample (multi-GPU batch sharding)
-        self.sample_lanes = 1        # concurrent sub-batches of sample() (see there); `bench.py --lanes N` overrides it
+        self.sample_lanes = None     # concurrent sub-batches of sample() (see there): None = two when the batch allows it;
+                                     # `bench.py --lanes N` / GSDD_SAMPLE_LANES override it
         self._graph_cache = {}
 
     @property
@@ -391,6 +433,24 @@ class DiffusionTransformer(nn.Module):
     def sample(self, condition_token, condition_mask, condition_embed, cf_condition_embed, content_token=None,
                filter_ratio=0.5, temperature=1.0, return_att_weight=False, return_logits=False, content_logits=None,
                print_log=True, use_graph=True, trace=None, **kwargs):
+        """diffusion_transformer.py:568-644.  The loop itself is `_sample_once`; this wrapper reads the layer kernel's range flags
+        once, after the loop (outside graph capture), and repeats the call on the bf16x3 layer kernel if an activation left the f16
+        operand range (Text2ImageTransformer.demote_to_x3p) -- same noise stream, so the tokens are those of an x3p run."""
+        args = (condition_token, condition_mask, condition_embed, cf_condition_embed)
+        kw = dict(content_token=content_token, filter_ratio=filter_ratio, return_logits=return_logits, use_graph=use_graph, **kwargs)
+        mark = len(trace) if trace is not None else 0
+        out = self._sample_once(*args, trace=trace, **kw)
+        if any(int(f.item()) != 0 for f in self._range_flags):
+            if not self.transformer.demote_to_x3p():
+                raise GsddError("non-finite activations in the denoiser (inf / NaN in the inputs or weights?)")
+            if trace is not None:
+                del trace[mark:]
+            self.noise_stream -= self.num_timesteps
+            out = self._sample_once(*args, trace=trace, **kw)
+        return out
+
+    def _sample_once(self, condition_token, condition_mask, condition_embed, cf_condition_embed, content_token=None,
+                     filter_ratio=0.5, return_logits=False, use_graph=True, trace=None, **kwargs):
         if int(self.num_timesteps * filter_ratio) != 0:
             raise NotImplementedError("only filter_ratio=0 (full-mask start) is used by the reference call site "
                                       "(discrete_diffusion.py:53-60)")
@@ -407,14 +467,16 @@ class DiffusionTransformer(nn.Module):
         # Independent sub-batches ("lanes") run their 100-step chains concurrently on separate HIP streams: every clip's chain
         # depends only on its own tokens, condition and noise rows (the noise key is the global row index), so the tokens are
         # those of the single-lane run, and workgroups of one lane fill the tail of the other lane's kernels.
-        lanes = int(kwargs.get("lanes", os.environ.get("GSDD_SAMPLE_LANES", self.sample_lanes)))
+        # Two lanes by default (measured +8.5 % at bs 16: BENCH_r02 extra.two_lanes); a lane keeps at least 4 clips.
+        lanes = kwargs.get("lanes", os.environ.get("GSDD_SAMPLE_LANES", self.sample_lanes))
+        lanes = 2 if lanes is None else int(lanes)
         lanes = lanes if (use_graph and trace is None and lanes > 1 and B % lanes == 0 and B // lanes >= 4) else 1
         # hipGraph capture is not allowed on the legacy default stream: the loop runs on side streams
         if getattr(self, "_streams", None) is None or len(self._streams) < lanes:
             self._streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         self._stream = self._streams[0]
         Bs = B // lanes
-        toks, graphs = [], []
+        toks, graphs, redo_counters, range_flags = [], [], [], []
         cur = torch.cuda.current_stream()
         tr.packed()                                 # packed weights, AdaLN tables and the fragment images are (re)built HERE, on the
         tr.fragment_images()                        # caller's stream: each lane's wait_stream(cur) below then orders its reads after them
@@ -427,9 +489,8 @@ class DiffusionTransformer(nn.Module):
                 Te = conds.shape[1]
                 condv = tr.cond_vectors(conds.contiguous())
                 ws = tr.workspace(rep * Bs, L, dev, rep=rep)
-                if ln == 0:
-                    self._last_ws = ws              # bench.py times the dominant kernel on operands of this shape
-                    self._last_run = (condv, Te, rep, Bs)
+                redo_counters.append(ws["redo"])
+                range_flags.append(ws["range"])
                 tok = torch.full((Bs, L), K, dtype=torch.int64, device=dev)               # all [MASK] (:613-618)
                 t2 = torch.full((rep * Bs,), T - 1, dtype=torch.int64, device=dev)
                 sid = torch.tensor([self.noise_stream], dtype=torch.int64, device=dev)
@@ -466,11 +527,18 @@ class DiffusionTransformer(nn.Module):
             cur.wait_stream(self._streams[ln])
             toks[ln].record_stream(cur)
         tok = toks[0] if lanes == 1 else torch.cat(toks, 0)
+        self._redo_counters = redo_counters     # attention chunk-redo events of this call, one device counter per lane
+        self._range_flags = range_flags
+        self._last_lanes = lanes
         self.noise_stream += T
         out = {"content_token": tok}
         if return_logits:
             raise NotImplementedError("return_logits is unused by the reference call sites")
         return out
+
+    def attention_redo_events(self):
+        """Chunk-redo events of the attention kernel during the last sample() call (synchronises: reads device counters)."""
+        return int(sum(int(c.item()) for c in getattr(self, "_redo_counters", [])))
 
     # ------------------------------------------------------------------ single-step pieces (parity tests, training glue)
     @torch.no_grad()
@@ -486,7 +554,7 @@ class DiffusionTransformer(nn.Module):
         ws = tr.workspace(rep * B, L, dev, rep=rep)
         condv = tr.cond_vectors(conds)
         t2 = torch.cat([t, t]).contiguous() if guided else t.contiguous()
-        logits = tr.run(tok.contiguous(), condv, conds.shape[1], t2.long(), ws, rep=rep)
+        logits = tr.run_checked(tok.contiguous(), condv, conds.shape[1], t2.long(), ws, rep=rep)
         sid = torch.tensor([stream_id], dtype=torch.int64, device=dev)
         out = torch.empty_like(tok)
         M = B * L
@@ -530,7 +598,7 @@ class DiffusionTransformer(nn.Module):
         tr = self.transformer
         ws = tr.workspace(B, L, dev)
         cond = cond_emb.float().contiguous()
-        logits = tr.run(xt, tr.cond_vectors(cond), cond.shape[1], t, ws)
+        logits = tr.run_checked(xt, tr.cond_vectors(cond), cond.shape[1], t, ws)
         aux_w = self.auxiliary_loss_weight if is_train else 0.0
         out = ops.d3pm_train_loss(logits, x0, xt, t, pt, sched, self.Lt_history, self.Lt_count, K=K, T=T,
                                   mask_weight=self.mask_weight, aux_weight=aux_w,

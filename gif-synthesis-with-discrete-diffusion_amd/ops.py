@@ -163,24 +163,18 @@ def small_linear(x, w, b, out=None, stream=None):
 
 def d3pm_attention_workspace(B, L, H, device):
     n = lib().gsdd_d3pm_attention_workspace_bytes(B, L, H)
-    return torch.empty((n // 4,), dtype=torch.float32, device=device)
+    return torch.empty(((n + 3) // 4,), dtype=torch.float32, device=device)
 
 
-def d3pm_attention(q, k, v, B, L, H, out, ws=None, stream=None):
-    """ws: scratch from d3pm_attention_workspace (matrix-pipe kernel); None -> workspace-free exact-f32 P.V kernel."""
+def d3pm_attention(q, k, v, B, L, H, out, ws=None, redo=None, stream=None):
+    """ws: scratch from d3pm_attention_workspace (matrix-pipe kernel); None -> workspace-free exact-f32 P.V kernel.
+    redo: optional int64[1] device counter of the kernel's chunk-redo events (caller-owned; see include/gsdd.h)."""
     nbytes = 0 if ws is None else ws.numel() * 4
-    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(ws), nbytes, stream_ptr(stream)))
+    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(ws), nbytes, ptr(redo), stream_ptr(stream)))
     return out
 
 
-def d3pm_attention_redo_count(reset=False):
-    """Redo events of the matrix-pipe attention kernel since the last reset (synchronises)."""
-    n = C.c_uint64()
-    check(lib().gsdd_d3pm_attention_redo_count(C.byref(n), int(reset)))
-    return int(n.value)
-
-
-def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, stream=None):
+def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, range_flag=None, stream=None):
     """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given).
     y = lay = None: only the next-block stage on x as it is (block 0, whose input is the embedding)."""
     d = LayerDesc()
@@ -197,6 +191,7 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None
         d.wqkv_x3 = ptr(nxt.get("wqkv_x3"))
         d.wqkv_h2 = ptr(nxt.get("wqkv_h2"))
         d.kv_img = ptr(kv_img)
+    d.range_flag = ptr(range_flag)
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
 
 

@@ -161,16 +161,17 @@ int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const floa
 /* Self-attention for head dim 4: q,k,v head-major [H][M][4] (M = B*L rows), out rows [M][H*4].
  * softmax(q k^T / sqrt(4)) v, scores never leave registers.
  * Replaces FullAttention.forward: transformer_utils.py:46-62 (head-mean att is dropped: unused). */
-/* workspace: gsdd_d3pm_attention_workspace_bytes(B,L,H) bytes of scratch for the pre-split K/V images of the
- * matrix-pipe kernel; NULL selects the workspace-free kernel (exact-f32 P.V on v_mfma_f32_4x4x1). */
+/* workspace: gsdd_d3pm_attention_workspace_bytes(B,L,H) bytes of scratch for the matrix-pipe kernel: the pre-split K image
+ * (32 B per key and head), the V image (32 B) and one f32 per (head, 32-key pair-tile) bounding the tile's largest ||k||, which
+ * lets the kernel prove from ||q|| ||k|| alone that a tile holds no probability above 2^-8 of its row sum (then only the f16 hi
+ * half of P is used for it).  NULL selects the workspace-free kernel (exact-f32 P.V on v_mfma_f32_4x4x1). */
 int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H);
-/* k = v = NULL: the workspace already holds the K / V images (written by gsdd_d3pm_layer through kv_img). */
+/* k = v = NULL: the workspace already holds the images and norms (written by gsdd_d3pm_layer through kv_img).
+ * redo_events: optional device counter (caller-owned, caller-zeroed) to which the kernel adds one per (wave, chunk) it had to
+ * redo with a larger exponent offset after an f16 overflow -- the kernel's only other data-dependent cost, 0 for near-uniform
+ * attention rows.  The library keeps no counter of its own (no hidden global state). */
 int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
-                        float* out, void* workspace, int64_t workspace_bytes, void* stream);
-/* Diagnostic counter of the matrix-pipe attention kernel: number of (wave, chunk) redo events since the last reset -- the
- * branch that restarts a 384-key chunk with a larger exponent offset after an f16 accumulator overflow; it is the only
- * data-dependent cost of the kernel (0 for near-uniform attention).  Synchronises with the device. */
-int gsdd_d3pm_attention_redo_count(uint64_t* count, int reset);
+                        float* out, void* workspace, int64_t workspace_bytes, uint64_t* redo_events, void* stream);
 
 /* Fused post-attention half of a denoiser block (n_embd 64, hidden 256), rows updated in place:
  *   x += proj(y)+b_proj+cvec[b];  x += W2 GELU2(W1 LN2(x)+b1)+b2;  [qkv_next = Wqkv AdaLN_next(x,t)+b_qkv, head-major]
@@ -202,6 +203,10 @@ typedef struct {
     const void* wqkv_h2;        /* wproj, and of the next block's wqkv.  Preferred over the bf16x3 images when given: all three    */
                                 /* weight matrices of the block are then LDS-resident and every product is 3 matrix instructions   */
                                 /* instead of 6; as accurate as an f32 GEMM with f32 accumulation (22-bit operands, exact products) */
+    int* range_flag;            /* optional device int (caller-zeroed), used by the f16 hi + lo kernel only: its operands are 16 a as  */
+                                /* f16, so an activation |a| >= 4094 overflows to inf.  The kernel sets *range_flag = 1 when a row of  */
+                                /* x it writes is not finite (inf / NaN propagate there); the caller then reruns with the bf16x3       */
+                                /* images, which have f32's range (d3pm.py does: checked once per sample(), outside graph capture)    */
 } gsdd_layer_desc;
 int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
 /* Pre-split w2 [64][256] + wproj [64][64] (-> layer_x3, GSDD_LAYER_X3_BYTES) and wqkv [192][64] (-> wqkv_x3,

@@ -35,14 +35,19 @@ def full_d3pm(G, seed, scale_weights):
     return dm.eval()
 
 
-def _oracle_step(od, tok, cond, t, sd, seed, stream, K):
-    """One guided reverse step of the oracle at full size -> (tokens, fp32 top-2 margin of the Gumbel scores, logits c / u)."""
+def _oracle_step(od, tok, cond, t, sd, seed, stream, K, first=False):
+    """One guided reverse step of the oracle at full size -> (tokens, fp32 top-2 margin of the Gumbel scores, logits c / u).
+    first: the all-[MASK] start of the reverse loop, whose log-one-hot has true -inf rows (diffusion_transformer.py:613-618)."""
     from oracle import philox
     B, L = tok.shape
     with torch.no_grad():
         want_c = od.denoiser(tok, cond, t, sd)
         want_u = od.denoiser(tok, torch.zeros_like(cond), t, sd)
-        log_xt = od.index_to_log_onehot(tok, K + 1)
+        if first:
+            log_xt = torch.full((B, K + 1, L), float("-inf"))
+            log_xt[:, -1] = 0
+        else:
+            log_xt = od.index_to_log_onehot(tok, K + 1)
         rec = od.cf_mix(od.predict_start_from_logits(want_c)[:, :-1], od.predict_start_from_logits(want_u)[:, :-1], 2.0)
         post = od.q_posterior(rec, log_xt, t, sd)
         u = torch.from_numpy(philox.uniform_bkl(seed, stream, B, K + 1, L))
@@ -53,9 +58,9 @@ def _oracle_step(od, tok, cond, t, sd, seed, stream, K):
 
 @pytest.mark.parametrize("scale_weights", [False, True])
 def test_full_size_denoiser_logits_and_step(G, scale_weights):
-    """L = 4096, K = 4096, 19 layers, both weight scales: logits within 1e-4 of the oracle, and a teacher-forced chain of THREE
-    guided reverse steps (the oracle's tokens of step s feed step s+1 on both sides, so one flipped arg-max cannot hide the next
-    steps): a token may differ from the oracle's only where the oracle's own top-2 margin is below 1e-5 -- the measured counts,
+    """L = 4096, K = 4096, 19 layers, both weight scales: logits within 1e-4 of the oracle, and FIVE guided reverse steps -- the loop's
+    first (t = 99, all [MASK]), a teacher-forced chain of three mid-chain steps (the oracle's tokens of step s feed step s+1 on both
+    sides, so one flipped arg-max cannot hide the next steps) and a late one (t = 5, mostly unmasked): a token may differ from the oracle's only where the oracle's own top-2 margin is below 1e-5 -- the measured counts,
     margins and errors go to the parity report."""
     from oracle import d3pm as od
     dm = full_d3pm(G, 0, scale_weights)
@@ -65,12 +70,25 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
     tok = torch.randint(0, K, (B, L), generator=g)
     tok[torch.rand(B, L, generator=g) < 0.5] = K
     cond = torch.randn(B, 1, 512, generator=g)
+    tok_mid = tok
+    tok_late = torch.randint(0, K, (B, L), generator=g)                 # t = 5: the chain's tail, 3 % of the positions still [MASK]
+    tok_late[torch.rand(B, L, generator=g) < 0.03] = K
     dm = dm.cuda()
     dm.set_noise(77)
     rec = {"steps": [], "logits_err": [], "logits_err_uncond": [], "mismatches": [], "min_margin": [], "mismatch_margins": []}
-    for s, step in enumerate((41, 40, 39)):
+    # the first step of the loop (t = 99, every position [MASK], -inf rows), three mid-chain steps, one late step
+    for s, step in enumerate((99, 41, 40, 39, 5)):
         t = torch.tensor([step])
-        want_tok, margin, want_c, want_u = _oracle_step(od, tok, cond, t, sd, 77, 3 + s, K)
+        if step == 99:
+            tok_in = torch.full((B, L), K, dtype=torch.int64)
+        elif step == 41:
+            tok_in = tok_mid
+        elif step == 5:
+            tok_in = tok_late
+        else:
+            tok_in = want_tok                                            # teacher forcing: continue from the oracle's tokens
+        tok = tok_in
+        want_tok, margin, want_c, want_u = _oracle_step(od, tok, cond, t, sd, 77, 3 + s, K, first=(step == 99))
         got_c = dm.transformer(tok.cuda(), cond.cuda(), t.cuda()).cpu()
         got_u = dm.transformer(tok.cuda(), torch.zeros_like(cond).cuda(), t.cuda()).cpu()
         err_c, err_u = (got_c - want_c).abs().max().item(), (got_u - want_u).abs().max().item()
@@ -79,7 +97,6 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
         rec["steps"].append(step); rec["logits_err"].append(err_c); rec["logits_err_uncond"].append(err_u)
         rec["mismatches"].append(int(mism.sum())); rec["min_margin"].append(margin.min().item())
         rec["mismatch_margins"].append(margin[mism].tolist())
-        tok = want_tok                                                   # teacher forcing: both sides continue from the oracle's tokens
     parity_report(f"full_size_d3pm_chain[scale_weights={scale_weights}]", rec)
     assert max(rec["logits_err"] + rec["logits_err_uncond"]) < 1e-4, rec
     for margins in rec["mismatch_margins"]:
@@ -175,3 +192,31 @@ def test_sampler_lanes_give_the_same_tokens(G):
         outs.append(dm.sample(["a"] * B, None, cond, cf, filter_ratio=0, lanes=lanes)["content_token"].cpu())
     assert torch.equal(outs[0], outs[1])
     assert (outs[0] < 256).all()
+
+
+def test_headline_shape_tokens(G):
+    """bench.py's own shape (config C3: B = 16, L = 4096, K = 4096, 19 layers, 100 graph-replayed guided steps): rows 0, 7 and 15 of
+    the batch equal three B = 1 runs keyed as global rows 0 / 7 / 15 (a batch-stride or row-offset slip would show here and nowhere
+    at B <= 2), two lanes equal one lane, every token is a code (< 4096: no [MASK] survives t = 0)."""
+    dm = full_d3pm(G, 0, False).cuda()
+    B, K = 16, 4096
+    g = torch.Generator().manual_seed(100)
+    cond = torch.randn(B, 1, 512, generator=g).cuda()
+    cf = torch.zeros_like(cond)
+    outs = {}
+    for lanes in (2, 1):
+        dm.set_noise(1234, 0, row_offset=0)
+        outs[lanes] = dm.sample(["x"] * B, None, cond, cf, filter_ratio=0, lanes=lanes)["content_token"].cpu()
+        assert dm._last_lanes == lanes
+    assert torch.equal(outs[1], outs[2])
+    tok = outs[2]
+    assert tok.dtype == torch.int64 and int(tok.min()) >= 0 and int(tok.max()) < K
+    singles = {}
+    for r in (0, 7, 15):
+        dm.set_noise(1234, 0, row_offset=r)
+        singles[r] = dm.sample(["x"], None, cond[r:r + 1], cf[r:r + 1], filter_ratio=0)["content_token"].cpu()[0]
+    mism = {r: int((singles[r] != tok[r]).sum()) for r in singles}
+    parity_report("headline_shape_tokens", {"B": B, "rows_checked": list(singles), "mismatches_vs_single_row_runs": list(mism.values()),
+                                            "lanes2_equals_lanes1": True, "max_token": int(tok.max()),
+                                            "distinct_codes": int(tok.unique().numel()), "redo_events": dm.attention_redo_events()})
+    assert all(v == 0 for v in mism.values()), mism

@@ -290,6 +290,39 @@ def test_d3pm_attention(G, B, L, spike, use_ws):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("case", ["flat", "hot_tile", "hot_query", "growing_norms", "zero_q"])
+def test_attention_norm_bound(G, case, monkeypatch):
+    """The adaptive mode's bound (kernel note in d3pm_attention.hip): tiles whose ||q|| ||k|| bound keeps every probability below 2^-8
+    of the row sum take the f16 hi half only, decided without looking at the scores.  Near-flat rows (the reference init) clear every
+    chunk after the first; a tile of large keys, or a query of large norm inside a sub-tile, must not be cleared: the result has to
+    stay within the kernel's 2e-5 of fp64 and within the adaptive mode's budget of the all-hi+lo result."""
+    B, L, H = 1, 4096, 16
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, H, L, 4, generator=g) * 0.15
+    k = torch.randn(B, H, L, 4, generator=g) * 0.15
+    v = torch.randn(B, H, L, 4, generator=g)
+    if case == "hot_tile":          # one late pair-tile of keys 40x the others, aligned with some queries: big probabilities there
+        k[:, :, 77 * 32:78 * 32] = q[:, :, 100:132] * 400.0
+    elif case == "hot_query":       # one query per sub-tile with a norm 30x its neighbours'
+        q[:, :, 5::16] *= 30.0
+    elif case == "growing_norms":
+        k = k * torch.linspace(0.5, 12.0, L).view(1, 1, L, 1)
+    elif case == "zero_q":
+        q[:, :, :64] = 0.0
+    want = attention_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, H * 4)
+    hm = lambda z: dev(z.permute(1, 0, 2, 3).reshape(H, B * L, 4).contiguous())
+    outs = {}
+    for mode in ("a8", "22"):
+        monkeypatch.setenv("GSDD_ATTN_P", mode)
+        out = torch.empty((B * L, H * 4), device="cuda")
+        G.ops.d3pm_attention(hm(q), hm(k), hm(v), B, L, H, out, ws=G.ops.d3pm_attention_workspace(B, L, H, "cuda"))
+        outs[mode] = out.cpu().double()
+    err = (outs["a8"] - want).abs().max().item()
+    dev22 = (outs["a8"] - outs["22"]).abs().max().item()
+    parity_report(f"attention_norm_bound_{case}", {"err_vs_fp64": err, "max_dev_from_hi_lo": dev22})
+    assert err < 2e-5 and dev22 < 2e-5, (err, dev22)
+
+
 def test_missing_cpu_fallback_is_loud(G):
     m = G.VQVAE(None, 8, 32, 16, 1, [1, 4, 4], 4, 16).eval()
     with pytest.raises(G.GsddError):
@@ -510,9 +543,52 @@ def test_fused_layer_variants_agree(G, monkeypatch):
         a_ref = torch.empty(M, Dm, device="cuda")
         G.ops.d3pm_attention(qkv2[:H], None, None, B2, L, H, a_img, ws=ws)
         q, k, v = ref[1][:H], ref[1][H:2 * H], ref[1][2 * H:]
-        G.ops.d3pm_attention(q, k, v, B2, L, H, a_ref, ws=G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda")))
+        ws_ref = G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda"))
+        G.ops.d3pm_attention(q, k, v, B2, L, H, a_ref, ws=ws_ref)
         torch.testing.assert_close(a_img, a_ref, atol=1e-6, rtol=0)
+        # the per-tile ||k|| bounds written by the layer kernel's epilogue == those of the pre-split pass, and both bound the keys
+        ntile = H * M // 32
+        kn_img, kn_ref = ws[H * M * 16:H * M * 16 + ntile], ws_ref[H * M * 16:H * M * 16 + ntile]
+        torch.testing.assert_close(kn_img, kn_ref, atol=0, rtol=1e-6)
+        true_max = k.double().norm(dim=-1).view(ntile, 32).max(dim=1).values
+        assert bool((kn_ref.double() >= true_max).all()) and bool((kn_ref.double() <= true_max * (1 + 1e-5) + 1e-30).all())
         monkeypatch.delenv("GSDD_LAYER", raising=False)
+
+
+def test_layer_kernel_range_screen_falls_back_to_bf16x3(G, golden, monkeypatch):
+    """The f16 hi + lo layer kernel carries activations as 16 a in f16: |a| >= 4094 overflows.  A hidden unit pushed to ~6000 (an
+    outlier MLP activation of a trained checkpoint) must not produce garbage: the kernel raises its range flag, the caller reruns on
+    the bf16x3 kernel (f32 range), and logits / sampled tokens are those of the CPU oracle resp. of a forced bf16x3 run."""
+    from oracle import d3pm as od
+    sd, a, cfg = golden("d3pm_L64")
+    sd = {k_: v_.clone() for k_, v_ in sd.items()}
+    sd["transformer.blocks.1.mlp.0.bias"][7] = 6000.0
+    dm = build_d3pm(G, sd, cfg)
+    tr = dm.transformer
+    xt, cond, t = dev(a["step_xt"]), dev(a["step_cond"]), dev(a["step_t"])
+    logits = tr(xt, cond, t)
+    assert getattr(tr, "range_demotions", 0) == 1 and "w2_x3" in tr.packed()["layers"][0] and "lay_h2" not in tr.packed()["layers"][0]
+    assert bool(torch.isfinite(logits).all())
+    with torch.no_grad():
+        want = od.denoiser(torch.from_numpy(a["step_xt"]), torch.from_numpy(a["step_cond"]), torch.from_numpy(a["step_t"]), sd)
+    torch.testing.assert_close(logits.cpu(), want, atol=LOGIT_TOL, rtol=1e-5)
+    # the sampler: flag read once after the captured loop, whole call repeated on the bf16x3 kernel with the same noise stream
+    B = cfg["B"]
+    dm2 = build_d3pm(G, sd, cfg)
+    dm2.set_noise(cfg["noise_seed"])
+    tok = dm2.sample(["a"] * B, None, cond, torch.zeros_like(cond), filter_ratio=0)["content_token"].cpu()
+    assert dm2.transformer.range_demotions == 1 and dm2.noise_stream == cfg["T"]
+    monkeypatch.setenv("GSDD_LAYER", "x3p")
+    dm3 = build_d3pm(G, sd, cfg)
+    dm3.set_noise(cfg["noise_seed"])
+    tok3 = dm3.sample(["a"] * B, None, cond, torch.zeros_like(cond), filter_ratio=0)["content_token"].cpu()
+    assert getattr(dm3.transformer, "range_demotions", 0) == 0
+    assert torch.equal(tok, tok3) and int(tok.max()) < cfg["K"]
+    monkeypatch.delenv("GSDD_LAYER")
+    # an unmodified model never trips the screen
+    dm4 = build_d3pm(G, golden("d3pm_L64")[0], cfg)
+    dm4.transformer(xt, cond, t)
+    assert getattr(dm4.transformer, "range_demotions", 0) == 0 and "lay_h2" in dm4.transformer.packed()["layers"][0]
 
 
 @pytest.mark.parametrize("L,spatial", [(48, [8, 8]), (96, [16, 8])])
