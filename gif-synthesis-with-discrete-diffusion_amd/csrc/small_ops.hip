@@ -236,6 +236,168 @@ __global__ __launch_bounds__(256) void nearest_code_kernel(const float* z, int64
     }
 }
 
+// ------------------------------------------------------------------ nearest code on the matrix cores (E = 128, K % 32 == 0)
+// z E^T as a GEMM on v_mfma_f32_32x32x2_f32 (exact f32: an fmaf chain, so the distances keep f32's meaning and the arg-min its
+// ties) with the arg-min as the epilogue; the (M, K) distance matrix never exists.  Computed transposed -- A = a 32-code tile,
+// B = 32 z rows -- so that a lane owns ONE z row and sixteen codes of the tile in increasing order: the running (best, index)
+// pair is two registers per row tile and "first minimum wins" is a strict compare.
+//   * z is register-resident: a wave keeps the B fragments of its 64 rows (2 x 64 VGPRs) for the whole sweep;
+//   * codes stream through LDS, one 32-code x 128 tile (16 KB) per step shared by the workgroup's 4 waves (256 rows),
+//     double-buffered, one barrier per tile; one ds_read_b128 feeds 4 k-steps of both row tiles (8 MFMAs);
+//   * ||e||^2 comes from a K-float vector made once per call (code_norm_kernel), not once per tile;
+//   * the codebook is split over `nsplit` workgroups per row block so that a 32768-row problem still fills 256 CUs; partial
+//     winners meet in idx[] itself as 64-bit keys (order-preserving bits of d << 32 | code) under atomicMin, which is exactly
+//     "smallest distance, then smallest index"; a last pass turns keys into indices and gathers zq.
+// d = (|z|^2 - 2 z.e) + |e|^2 in that association, |z|^2 and |e|^2 summed in index order, as in nearest_code_kernel.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NCM_E = 128, NCM_EP = NCM_E + 4;
+
+__global__ __launch_bounds__(256) void code_norm_kernel(const float* __restrict__ cb, int K, int E, float* __restrict__ en) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int e = 0; e < E; e += 4) {
+        const float4 c = *reinterpret_cast<const float4*>(cb + (int64_t)k * E + e);
+        s += c.x * c.x; s += c.y * c.y; s += c.z * c.z; s += c.w * c.w;
+    }
+    en[k] = s;
+}
+
+__global__ __launch_bounds__(256) void nearest_code_keys_init_kernel(unsigned long long* keys, int64_t M) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < M) keys[m] = ~0ull;
+}
+
+__device__ __forceinline__ unsigned long long nc_key(float d, int code) {
+    uint32_t u = __float_as_uint(d);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;                 // unsigned order == float order (negative zero below zero: harmless)
+    return ((unsigned long long)u << 32) | (uint32_t)code;
+}
+
+__global__ __launch_bounds__(256, 2) void nearest_code_mfma_kernel(const float* __restrict__ z, int64_t M, const float* __restrict__ cb,
+                                                                    const float* __restrict__ en, int codes_per_split, int nrb,
+                                                                    unsigned long long* __restrict__ keys) {
+    __shared__ __attribute__((aligned(16))) float scb[2][32][NCM_EP];
+    __shared__ __attribute__((aligned(16))) float sen[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int rb = blockIdx.x % nrb, split = blockIdx.x / nrb;
+    const int64_t m0 = (int64_t)rb * 256 + wave * 64;
+    const int c0 = split * codes_per_split, ntiles = codes_per_split >> 5;
+
+    // B fragments of the wave's two row tiles: lane (row li, half lh) holds z[row][8 t + 4 lh .. + 3] for t = 0..15 -- the k-steps
+    // of the t-th ds_read_b128 of a code tile contract k = 8 t + j and 8 t + 4 + j (j = 0..3)
+    float4 zf[2][NCM_E / 8];
+    float zn[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int64_t m = m0 + 32 * rt + li;
+        const float* zr = z + (m < M ? m : M - 1) * NCM_E;
+        float sacc = 0.f;                                         // |z|^2 in index order (both halves compute their row's: same value)
+#pragma unroll 4
+        for (int e = 0; e < NCM_E; e += 4) {
+            const float4 c = *reinterpret_cast<const float4*>(zr + e);
+            sacc += c.x * c.x; sacc += c.y * c.y; sacc += c.z * c.z; sacc += c.w * c.w;
+        }
+        zn[rt] = sacc;
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // (keeps the 128 fragment registers below out of the loops above)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int64_t m = m0 + 32 * rt + li;
+        const float* zr = z + (m < M ? m : M - 1) * NCM_E;
+#pragma unroll
+        for (int t = 0; t < NCM_E / 8; ++t) zf[rt][t] = *reinterpret_cast<const float4*>(zr + 8 * t + 4 * lh);
+    }
+
+    // staging: a tile is 32 codes x 32 float4 = 1024 float4, four per thread, all requested together and one tile ahead
+    float4 stg[4];
+    float sten = 0.f;
+    auto load_tile = [&](int tile) {
+        const float* src = cb + (int64_t)(c0 + 32 * tile) * NCM_E;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) stg[it] = *reinterpret_cast<const float4*>(src + (int64_t)(tid + 256 * it) * 4);
+        if (tid < 32) sten = en[c0 + 32 * tile + tid];
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + 256 * it;
+            *reinterpret_cast<float4*>(&scb[buf][i >> 5][(i & 31) * 4]) = stg[it];
+        }
+        if (tid < 32) sen[buf][tid] = sten;
+    };
+    float best[2] = {INFINITY, INFINITY};
+    int bidx[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) load_tile(tile + 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        // one fragment read ahead of its 8 MFMAs, pinned: left to itself the scheduler hoists all 16 reads (64 registers) and spills
+        float4 a = *reinterpret_cast<const float4*>(&scb[buf][li][4 * lh]);
+#pragma unroll
+        for (int t = 0; t < NCM_E / 8; ++t) {
+            const float4 an = *reinterpret_cast<const float4*>(&scb[buf][li][8 * (t + 1 < NCM_E / 8 ? t + 1 : t) + 4 * lh]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zf[0][t].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zf[1][t].x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zf[0][t].y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zf[1][t].y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zf[0][t].z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zf[1][t].z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zf[0][t].w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zf[1][t].w, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then this step's eight MFMAs
+            a = an;
+        }
+        // lane holds, of each row tile, its row li against codes 8 (r >> 2) + 4 lh + (r & 3): increasing in r
+        const int cbase = c0 + 32 * tile + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 e4 = *reinterpret_cast<const float4*>(&sen[buf][8 * q + 4 * lh]);
+            const float ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int code = cbase + 8 * q + rr;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const float dd = (zn[rt] - 2.f * acc[rt][4 * q + rr]) + ee[rr];
+                    if (dd < best[rt]) { best[rt] = dd; bidx[rt] = code; }
+                }
+            }
+        }
+        if (tile + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const float ob = __shfl_xor(best[rt], 32);
+        const int oi = __shfl_xor(bidx[rt], 32);
+        if (ob < best[rt] || (ob == best[rt] && oi < bidx[rt])) { best[rt] = ob; bidx[rt] = oi; }
+        const int64_t m = m0 + 32 * rt + li;
+        if (lh == 0 && m < M && bidx[rt] != 0x7FFFFFFF) atomicMin(&keys[m], nc_key(best[rt], bidx[rt]));
+    }
+}
+
+__global__ __launch_bounds__(256) void nearest_code_finish_kernel(int64_t* idx, int64_t M, int E, const float* __restrict__ cb,
+                                                                  float* __restrict__ zq) {
+    // 16 threads per row: key -> index (a row whose distances were all NaN never won a compare: index 0, as the VALU kernel), zq gather
+    const int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (m >= M) return;
+    const unsigned long long key = reinterpret_cast<const unsigned long long*>(idx)[m];
+    const int code = key == ~0ull ? 0 : (int)(uint32_t)key;
+    __syncthreads();
+    if ((threadIdx.x & 15) == 0) idx[m] = code;
+    if (zq != nullptr)
+        for (int e = (threadIdx.x & 15) * 4; e < E; e += 64)
+            *reinterpret_cast<float4*>(zq + m * E + e) = *reinterpret_cast<const float4*>(cb + (int64_t)code * E + e);
+}
+
 // ------------------------------------------------------------------ clip preprocessing (ucf101_dataset.py:105-140)
 // uint8 THWC frames -> normalised (x/255 - mean)/std, bilinear resize of the shorter side to R (align_corners = false, PyTorch's
 // source-index rule with one rounding: src = max(fma(in/out, dst + 0.5, -0.5), 0)), centre crop, CTHW float32.  One thread per
@@ -333,12 +495,31 @@ extern "C" int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W
     return GSDD_OK;
 }
 
+extern "C" int64_t gsdd_nearest_code_workspace_bytes(int K) { return (int64_t)K * 4; }
+
 extern "C" int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K, int64_t* idx, float* zq,
-                                 void* stream) {
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
     GSDD_CHECK_ARG(z && cb && idx, "null pointer");
     GSDD_CHECK_ARG(M > 0 && K > 0 && E > 0 && E % 4 == 0 && E <= 256, "E must be a multiple of 4, <= 256");
+    hipStream_t st = (hipStream_t)stream;
+    static const bool force_valu = getenv("GSDD_NEAREST_VALU") != nullptr;               // A/B switch
+    if (E == NCM_E && K % 32 == 0 && workspace != nullptr && !force_valu) {
+        GSDD_CHECK_ARG(workspace_bytes >= gsdd_nearest_code_workspace_bytes(K), "workspace too small");
+        GSDD_CHECK_ARG(M < (1ll << 31) * 16, "too many rows");
+        float* en = reinterpret_cast<float*>(workspace);
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(idx);
+        const int nrb = (int)((M + 255) / 256);
+        int nsplit = 1;                                        // enough workgroups for two rounds of 2 per CU, tiles of 32 codes
+        while (nrb * nsplit < 1024 && nsplit * 2 <= K / 32 && (K / (nsplit * 2)) % 32 == 0) nsplit *= 2;
+        hipLaunchKernelGGL(code_norm_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, cb, K, E, en);
+        hipLaunchKernelGGL(nearest_code_keys_init_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, keys, M);
+        hipLaunchKernelGGL(nearest_code_mfma_kernel, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, M, cb, en, K / nsplit, nrb, keys);
+        hipLaunchKernelGGL(nearest_code_finish_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, st, idx, M, E, cb, zq);
+        GSDD_CHECK_LAUNCH();
+        return GSDD_OK;
+    }
     const size_t lds = (size_t)2 * NC_T * (E + 4) * sizeof(float);
-    hipLaunchKernelGGL(nearest_code_kernel, dim3((unsigned)((M + NC_T - 1) / NC_T)), dim3(256), lds, (hipStream_t)stream, z,
+    hipLaunchKernelGGL(nearest_code_kernel, dim3((unsigned)((M + NC_T - 1) / NC_T)), dim3(256), lds, st, z,
                        M, E, cb, K, idx, zq);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;

@@ -84,9 +84,13 @@ def axial_attention(qkv, dims, C_, n_head, out, stream=None):
     return out
 
 
-def nearest_code(z, cb, idx, zq=None, stream=None):
-    check(lib().gsdd_nearest_code(ptr(z), z.shape[0], z.shape[1], ptr(cb), cb.shape[0], ptr(idx), ptr(zq),
-                                  stream_ptr(stream)))
+def nearest_code(z, cb, idx, zq=None, stream=None, matrix=True):
+    """matrix=False: no workspace -> the register-tiled vector kernel whatever the shape (tests compare the two)."""
+    ws = None
+    if matrix:
+        ws = torch.empty((lib().gsdd_nearest_code_workspace_bytes(cb.shape[0]) // 4,), dtype=torch.float32, device=z.device)
+    check(lib().gsdd_nearest_code(ptr(z), z.shape[0], z.shape[1], ptr(cb), cb.shape[0], ptr(idx), ptr(zq), ptr(ws),
+                                  0 if ws is None else ws.numel() * 4, stream_ptr(stream)))
     return idx
 
 

@@ -92,9 +92,13 @@ int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W, int C, in
 
 /* Nearest codebook entry: idx[m] = argmin_k (|z_m|^2 - 2 z_m.e_k + |e_k|^2), first minimum wins.
  * Replaces Codebook.forward distance+argmin: videogpt_vq_vae.py:178-183.
- * z: [M][E] rows, cb: [K][E]; optional zq[M][E] = cb[idx] (the F.embedding at :186). */
+ * z: [M][E] rows, cb: [K][E]; optional zq[M][E] = cb[idx] (the F.embedding at :186).
+ * workspace: gsdd_nearest_code_workspace_bytes(K) bytes (the |e_k|^2 vector).  With it, E == 128 and K % 32 == 0 the distances
+ * are a GEMM on the f32 matrix cores with the arg-min as its epilogue (never materialised); otherwise, or with workspace ==
+ * NULL, the register-tiled vector kernel runs (any E % 4 == 0, any K). */
+int64_t gsdd_nearest_code_workspace_bytes(int K);
 int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K,
-                      int64_t* idx, float* zq, void* stream);
+                      int64_t* idx, float* zq, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ VQ-VAE train-mode forward pieces
  * nn.BatchNorm3d in train mode on rows x[M][C] (videogpt_vq_vae.py:125-133, 242-247): batch mean / biased variance ->

@@ -133,6 +133,39 @@ def test_nearest_code_vs_oracle(G):
     idx2 = torch.empty(M, dtype=torch.int64, device="cuda")
     G.ops.nearest_code(dev(z), dev(cb2), idx2, None)
     assert (idx2 < 8).all()
+    # the same on the matrix-core kernel (K % 32 == 0): the duplicate halves sit in different codebook splits / workgroups
+    cb3 = torch.cat([cb[:2048], cb[:2048]], 0)
+    idx3 = torch.empty(M, dtype=torch.int64, device="cuda")
+    G.ops.nearest_code(dev(z), dev(cb3), idx3, None)
+    assert (idx3 < 2048).all()
+
+
+@pytest.mark.parametrize("M", [32768, 4096 + 77, 64])
+def test_nearest_code_matrix_kernel(G, M):
+    """The matrix-core kernel (z E^T on v_mfma_f32_32x32x2_f32, arg-min epilogue, codebook split over workgroups, 64-bit-key merge)
+    against the register-tiled vector kernel and fp64: C2's shape (32768 latents x 4096 codes x 128), a ragged row count, a tiny one.
+    The two kernels sum the 128 products in different orders, so they may differ where the fp32 distances are a near-tie."""
+    g = torch.Generator().manual_seed(M)
+    E, K = 128, 4096
+    z = torch.randn(M, E, generator=g)
+    cb = torch.randn(K, E, generator=g) * 0.7 + 0.3 * z[torch.randint(0, M, (K,), generator=g)]     # codes near latents: tight races
+    zd, cd = dev(z), dev(cb)
+    idx_m = torch.empty(M, dtype=torch.int64, device="cuda")
+    idx_v = torch.empty(M, dtype=torch.int64, device="cuda")
+    zq = torch.empty(M, E, device="cuda")
+    G.ops.nearest_code(zd, cd, idx_m, zq)
+    G.ops.nearest_code(zd, cd, idx_v, None, matrix=False)
+    d64 = (zd.double() ** 2).sum(1, keepdim=True) - 2 * zd.double() @ cd.double().t() + (cd.double() ** 2).sum(1)[None]
+    top2 = torch.topk(d64, 2, dim=1, largest=False)
+    margin = (top2.values[:, 1] - top2.values[:, 0]).cpu()
+    want = top2.indices[:, 0]
+    mm, mv = (idx_m != want).cpu(), (idx_v != want).cpu()
+    parity_report(f"nearest_code_matrix_kernel[M={M}]", {"mismatches_vs_fp64": int(mm.sum()), "vector_kernel_mismatches_vs_fp64": int(mv.sum()),
+                                                         "kernels_differ": int((idx_m != idx_v).sum()), "min_margin": margin.min().item(),
+                                                         "mismatch_margins": margin[mm].tolist()})
+    assert 0 <= int(idx_m.min()) and int(idx_m.max()) < K
+    assert all(x < 2e-4 for x in margin[mm].tolist()), margin[mm].tolist()     # distances ~2e2: an fp32 ulp is 1.5e-5
+    assert torch.equal(zq, cd[idx_m])
 
 
 # ----------------------------------------------------------------------------- D3PM vs reference fixtures
@@ -301,8 +334,8 @@ def test_attention_norm_bound(G, case, monkeypatch):
     q = torch.randn(B, H, L, 4, generator=g) * 0.15
     k = torch.randn(B, H, L, 4, generator=g) * 0.15
     v = torch.randn(B, H, L, 4, generator=g)
-    if case == "hot_tile":          # one late pair-tile of keys 40x the others, aligned with some queries: big probabilities there
-        k[:, :, 77 * 32:78 * 32] = q[:, :, 100:132] * 400.0
+    if case == "hot_tile":          # one late pair-tile of keys 15x the others, aligned with some queries: probabilities of a few
+        k[:, :, 77 * 32:78 * 32] = q[:, :, 100:132] * 100.0       # percent of their rows there, 1/4096 everywhere else
     elif case == "hot_query":       # one query per sub-tile with a norm 30x its neighbours'
         q[:, :, 5::16] *= 30.0
     elif case == "growing_norms":

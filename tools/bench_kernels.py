@@ -208,5 +208,16 @@ def main():
             print(f"d3pm_step B={Bs} K={Ks}: {ms:.3f} ms  {by / ms / 1e6:.0f} GB/s algorithmic  {ms * 1e6 / (Mh * Ks) * 1e3:.2f} ps/element")
             del logits
 
+    if "nearest" in which:
+        for Mn in (32768, 262144):                     # C2 at bs 8 (one encode of the bench's decode batch) and at bs 64
+            z = torch.randn((Mn, 128), device=dev)
+            cb = torch.randn((4096, 128), device=dev)
+            idx = torch.empty((Mn,), dtype=torch.int64, device=dev)
+            fl = 2.0 * Mn * 4096 * 128
+            for name, mat in (("matrix cores", True), ("vector kernel", False)):
+                ms = timeit(lambda: ops.nearest_code(z, cb, idx, None, matrix=mat))
+                print(f"nearest_code M={Mn} K=4096 E=128 {name}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 157.3 * 100:.1f}% of f32 MFMA peak)")
+
+
 if __name__ == "__main__":
     main()
