@@ -9,4 +9,5 @@ from . import ops  # noqa: F401
 from ._lib import GsddError, LIB_PATH, EXPORTS, lib  # noqa: F401
 from .d3pm import (DalleMaskImageEmbedding, DiffusionTransformer, DiscreteDiffusion,  # noqa: F401
                    Text2ImageTransformer)
+from .i3d import InceptionI3d  # noqa: F401
 from .vqvae import VQVAE  # noqa: F401

@@ -12,7 +12,7 @@ _lib = None
 
 EXPORTS = [
     "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows", "gsdd_preprocess_clip",
-    "gsdd_axial_attention", "gsdd_nearest_code", "gsdd_nearest_code_workspace_bytes", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
+    "gsdd_axial_attention", "gsdd_pool3d", "gsdd_nearest_code", "gsdd_nearest_code_workspace_bytes", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
     "gsdd_codebook_ema", "gsdd_code_perplexity", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
     "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_layer_pack", "gsdd_d3pm_layer_pack_h2", "gsdd_rows_linear_pack_many", "gsdd_rows_linear", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_gelu2", "gsdd_ln_fwd", "gsdd_ln_bwd", "gsdd_wgrad",
@@ -87,6 +87,7 @@ def lib():
         L.gsdd_ncdhw_to_rows.argtypes = [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]
         L.gsdd_preprocess_clip.argtypes = [_p] + [_i] * 10 + [_p, _p]
         L.gsdd_axial_attention.argtypes = [_p, _i, _i, _i, _i, _i, _i, _p, _p]
+        L.gsdd_pool3d.argtypes = [_p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _p, _i, _p]
         L.gsdd_nearest_code.argtypes = [_p, _i64, _i, _p, _i, _p, _p, _p, _i64, _p]
         L.gsdd_nearest_code_workspace_bytes.argtypes = [_i]
         L.gsdd_nearest_code_workspace_bytes.restype = _i64

@@ -398,6 +398,54 @@ __global__ __launch_bounds__(256) void nearest_code_finish_kernel(int64_t* idx, 
             *reinterpret_cast<float4*>(zq + m * E + e) = *reinterpret_cast<const float4*>(cb + (int64_t)code * E + e);
 }
 
+// ------------------------------------------------------------------ 3-D pooling on channels-last rows (I3D: pytorch_i3d.py:7-34, 296)
+// out[n][to][ho][wo][c] = max / mean over the (kt, kh, kw) window starting at (to st - pt, ho sh - ph, wo sw - pw).  Positions outside
+// the input count as ZERO in the maximum: MaxPool3dSamePadding pads with F.pad's zeros and then pools with padding = 0, so a border
+// window of all-negative values yields 0, not their maximum.  The mean divides by the full window (AvgPool3d's count_include_pad
+// default; the reference only uses it unpadded).  One thread per (output position, 4 channels): 16-byte loads along c.
+struct PoolArgs {
+    const float* in; float* out;
+    int N, Di, Hi, Wi, C, in_pitch;
+    int Do, Ho, Wo, out_pitch;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw;
+    int mode;                        // 0 max, 1 mean
+};
+__global__ __launch_bounds__(256) void pool3d_kernel(const PoolArgs a) {
+    const int c4n = a.C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.N * a.Do * a.Ho * a.Wo * c4n;
+    if (i >= total) return;
+    const int c4 = (int)(i % c4n);
+    int64_t r = i / c4n;
+    const int wo = (int)(r % a.Wo); r /= a.Wo;
+    const int ho = (int)(r % a.Ho); r /= a.Ho;
+    const int to = (int)(r % a.Do);
+    const int n = (int)(r / a.Do);
+    const bool mx = a.mode == 0;
+    float4 acc = mx ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bool padded = false;
+    for (int dt = 0; dt < a.kt; ++dt) {
+        const int ti = to * a.st - a.pt + dt;
+        for (int dh = 0; dh < a.kh; ++dh) {
+            const int hi = ho * a.sh - a.ph + dh;
+            for (int dw = 0; dw < a.kw; ++dw) {
+                const int wi = wo * a.sw - a.pw + dw;
+                if (ti < 0 || ti >= a.Di || hi < 0 || hi >= a.Hi || wi < 0 || wi >= a.Wi) { padded = true; continue; }
+                const float4 v = *reinterpret_cast<const float4*>(a.in + ((((int64_t)n * a.Di + ti) * a.Hi + hi) * a.Wi + wi) * a.in_pitch + 4 * c4);
+                if (mx) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+                else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            }
+        }
+    }
+    if (mx) {
+        if (padded) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    } else {
+        const float inv = 1.f / (float)(a.kt * a.kh * a.kw);
+        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    }
+    *reinterpret_cast<float4*>(a.out + ((((int64_t)n * a.Do + to) * a.Ho + ho) * a.Wo + wo) * a.out_pitch + 4 * c4) = acc;
+}
+
 // ------------------------------------------------------------------ clip preprocessing (ucf101_dataset.py:105-140)
 // uint8 THWC frames -> normalised (x/255 - mean)/std, bilinear resize of the shorter side to R (align_corners = false, PyTorch's
 // source-index rule with one rounding: src = max(fma(in/out, dst + 0.5, -0.5), 0)), centre crop, CTHW float32.  One thread per
@@ -521,6 +569,27 @@ extern "C" int gsdd_nearest_code(const float* z, int64_t M, int E, const float* 
     const size_t lds = (size_t)2 * NC_T * (E + 4) * sizeof(float);
     hipLaunchKernelGGL(nearest_code_kernel, dim3((unsigned)((M + NC_T - 1) / NC_T)), dim3(256), lds, st, z,
                        M, E, cb, K, idx, zq);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
+
+extern "C" int gsdd_pool3d(const float* in, int N, int Di, int Hi, int Wi, int C, int in_pitch, const int* kernel, const int* stride,
+                           const int* pad_front, int Do, int Ho, int Wo, int mode, float* out, int out_pitch, void* stream) {
+    GSDD_CHECK_ARG(in && out && kernel && stride && pad_front, "null pointer");
+    GSDD_CHECK_ARG(N > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "bad sizes");
+    GSDD_CHECK_ARG(C > 0 && C % 4 == 0 && in_pitch % 4 == 0 && out_pitch % 4 == 0 && in_pitch >= C && out_pitch >= C, "C and the pitches must be multiples of 4");
+    GSDD_CHECK_ARG(mode == 0 || mode == 1, "mode: 0 max, 1 mean");
+    for (int i = 0; i < 3; ++i) GSDD_CHECK_ARG(kernel[i] > 0 && stride[i] > 0 && pad_front[i] >= 0, "bad window");
+    PoolArgs a;
+    a.in = in; a.out = out; a.N = N; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.C = C; a.in_pitch = in_pitch;
+    a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.out_pitch = out_pitch;
+    a.kt = kernel[0]; a.kh = kernel[1]; a.kw = kernel[2]; a.st = stride[0]; a.sh = stride[1]; a.sw = stride[2];
+    a.pt = pad_front[0]; a.ph = pad_front[1]; a.pw = pad_front[2]; a.mode = mode;
+    // every window must start inside the (virtually padded) input and touch at least one real position
+    GSDD_CHECK_ARG((Do - 1) * a.st - a.pt < Di && (Ho - 1) * a.sh - a.ph < Hi && (Wo - 1) * a.sw - a.pw < Wi, "output grid outside the input");
+    const int64_t total = (int64_t)N * Do * Ho * Wo * (C / 4);
+    GSDD_CHECK_ARG(total < (1ll << 31) * 256, "too many outputs");
+    hipLaunchKernelGGL(pool3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     GSDD_CHECK_LAUNCH();
     return GSDD_OK;
 }

@@ -84,6 +84,17 @@ def axial_attention(qkv, dims, C_, n_head, out, stream=None):
     return out
 
 
+def pool3d(x, dims, C_, kernel, stride, pad_front, out_grid, out, *, mode="max", in_pitch=None, out_pitch=None, stream=None):
+    """Channels-last 3-D pooling (gsdd_pool3d).  x: rows [N*Di*Hi*Wi][in_pitch] (C_ pooled channels), out: rows of out_pitch floats
+    (may be a channel slice view's flat tail of a wider buffer)."""
+    N, Di, Hi, Wi = dims
+    k, s_, p = (C.c_int * 3)(*kernel), (C.c_int * 3)(*stride), (C.c_int * 3)(*pad_front)
+    check(lib().gsdd_pool3d(ptr(x), N, Di, Hi, Wi, C_, in_pitch if in_pitch is not None else C_, k, s_, p, out_grid[0], out_grid[1],
+                            out_grid[2], 0 if mode == "max" else 1, ptr(out), out_pitch if out_pitch is not None else C_,
+                            stream_ptr(stream)))
+    return out
+
+
 def nearest_code(z, cb, idx, zq=None, stream=None, matrix=True):
     """matrix=False: no workspace -> the register-tiled vector kernel whatever the shape (tests compare the two)."""
     ws = None

@@ -100,6 +100,14 @@ int64_t gsdd_nearest_code_workspace_bytes(int K);
 int gsdd_nearest_code(const float* z, int64_t M, int E, const float* cb, int K,
                       int64_t* idx, float* zq, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* 3-D max / mean pooling on channels-last rows, for the FVD evaluator's I3D feature extractor (MaxPool3dSamePadding and the
+ * final AvgPool3d: src/models/motionencoder/pytorch_i3d.py:7-34, :296).  in: N x Di x Hi x Wi positions of `in_pitch` floats, C of
+ * them pooled; window kernel[3] / stride[3] starting at o * stride - pad_front; out grid Do x Ho x Wo with row pitch out_pitch
+ * (a channel slice of a wider concatenated row is addressed by offsetting `out`).  mode 0: maximum, positions outside the input
+ * count as 0 (the reference zero-pads, then pools unpadded); mode 1: mean over the full window. */
+int gsdd_pool3d(const float* in, int N, int Di, int Hi, int Wi, int C, int in_pitch, const int* kernel, const int* stride,
+                const int* pad_front, int Do, int Ho, int Wo, int mode, float* out, int out_pitch, void* stream);
+
 /* ------------------------------------------------------------------ VQ-VAE train-mode forward pieces
  * nn.BatchNorm3d in train mode on rows x[M][C] (videogpt_vq_vae.py:125-133, 242-247): batch mean / biased variance ->
  * folded scale = w/sqrt(var+eps), shift = b - mean*scale (consumed by gsdd_gemm's pro_scale/pro_shift); running stats

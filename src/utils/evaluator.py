@@ -1,8 +1,11 @@
 """FVD evaluator with the reference's interface (src/utils/evaluator.py:10-116): push_vals(batch, batch_idx, outputs) ->
 evaluate_metrics(...) -> {'fvd': ...} -> reset().  The statistic is gsdd_amd.metrics.frechet_distance (pinned to values of the
-reference's function, tests/golden/frechet.npz).  The reference's feature extractor is a Kinetics-400 I3D
-(src/models/motionencoder/pytorch_i3d.py) fed with clips de-normalised, resized to 224 and scaled to [-1, 1]; its weights cannot
-be obtained offline, so `videoencoder` may be any module (or config of one) mapping (B,3,T,H,W) clips to features."""
+reference's function, tests/golden/frechet.npz).  The feature extractor is the reference's Kinetics-400 I3D
+(src/models/motionencoder/pytorch_i3d.py -> gsdd_amd/i3d.py: the same architecture and state_dict keys on the HIP conv path,
+pinned to the reference module on seeded weights) fed with clips de-normalised, resized to 224 and scaled to [-1, 1]; its
+pretrained weights cannot be obtained offline, so `checkpoint_paths` must point at a supplied state_dict (or `videoencoder` at
+any other module mapping (B,3,T,H,W) clips to features).  Unlike the reference (which never leaves train mode here:
+evaluator.py:14-29), the extractor runs in eval mode."""
 import torch
 
 from gsdd_amd.hydra_lite import instantiate
@@ -32,6 +35,10 @@ class Evaluator:
         self.videoencoder = instantiate(videoencoder, _recursive_=False) if isinstance(videoencoder, dict) else videoencoder
         if checkpoint_paths and checkpoint_paths != "__None__":
             self.videoencoder.load_state_dict(torch.load(checkpoint_paths, map_location="cpu", weights_only=True))
+        elif any(True for _ in self.videoencoder.parameters()):
+            import warnings
+            warnings.warn("Evaluator: no checkpoint for the video encoder (model.evaluator.checkpoint_paths / eval_ckpt): it runs on its "
+                          "random initialisation, and the distance it yields is not an FVD", UserWarning)
         self.videoencoder.to(device).eval()
         self.reset()
 

@@ -74,7 +74,7 @@ def test_c2_vqvae_training_step_full_size(G):
         perm = torch.randperm(B * 16 * 16 * 16, generator=torch.Generator().manual_seed(3))
         vq.perm_source = lambda n: perm
         trainer = VQVAETrainer(vq, lr=4e-4)
-        for i in range(3 if run == 0 else 1):
+        for i in range(6 if run == 0 else 1):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = trainer.step(x)
@@ -84,8 +84,11 @@ def test_c2_vqvae_training_step_full_size(G):
             (losses if run == 0 else first).append(total)
         del trainer, vq
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    parity_report("c2_vqvae_train_full_size", {"losses": losses, "first_step_again": first[0], "ms_per_step": ms[1:3], "peak_gib": peak})
+    parity_report("c2_vqvae_train_full_size", {"losses": losses, "first_step_again": first[0], "ms_per_step": ms[1:6], "peak_gib": peak})
     assert all(torch.isfinite(torch.tensor(losses)))
-    assert losses[2] < losses[0], losses                      # (step 1 re-initialises nothing: the codebook was seeded by step 0)
+    # losses[1] > losses[0] is the recipe, not the kernels: Adam's first update is lr * sign(g) on all 28.9 M weights at once (the
+    # CPU oracle + torch.optim.Adam show the same jump: test_c2_loss_trajectory_matches_torch_adam_at_full_size); from there it falls
+    assert all(b < a for a, b in zip(losses[1:], losses[2:])), losses
+    assert losses[5] < losses[0], losses
     assert abs(first[0] - losses[0]) <= 1e-6 * abs(losses[0]), (first, losses)
     assert peak < 60.0, peak

@@ -70,8 +70,10 @@ def test_compose_and_instantiate_reference_targets(monkeypatch):
     assert m1.generator.n_codes == 4096 and len(o1) == 1 and sched == [] and o1[0].defaults["lr"] == 4e-4
     dm = instantiate(compose(os.path.join(REPO, "configs"), "train.yaml", ["datamodule=msrvtt"] + SMALL).datamodule)
     assert type(dm).__name__ == "MSRVTTDataModule" and dm.sequence_length == 4
-    with pytest.raises(NotImplementedError, match="do_evaluation"):
-        instantiate(cfg.model.evaluator, device="cpu", _recursive_=False)
+    with pytest.warns(UserWarning, match="no checkpoint"):             # the I3D extractor exists now; without weights its FVD means nothing
+        ev = instantiate(cfg.model.evaluator, device="cpu", _recursive_=False)
+    assert type(ev.videoencoder).__name__ == "InceptionI3d" and not ev.videoencoder.training
+    assert len(ev.videoencoder.state_dict()) == 344
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="the reference tree only exists in the build container")

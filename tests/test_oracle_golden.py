@@ -244,3 +244,45 @@ def test_glue_oracle_matches_reference(golden, tag):
     np.testing.assert_allclose(test.numpy(), a[f"{tag}/test"], atol=2e-5, rtol=1e-5)
 
 
+
+
+# ----------------------------------------------------------------------------- I3D (FVD feature extractor)
+def i3d_fixture():
+    """-> (npz, seeded state_dict over the reference's keys): the weights are rebuilt from the fixture's seed, not stored."""
+    import os
+    from oracle import i3d as oi
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "i3d.npz"), allow_pickle=False)
+    keys = [(str(k), tuple(int(v) for v in s[:n])) for k, s, n in zip(z["keys"], z["shapes"], z["ndims"])]
+    return z, oi.seeded_state_dict(keys, int(z["weight_seed"]))
+
+
+def test_i3d_oracle_matches_reference_outputs():
+    """oracle/i3d.py against outputs of the reference's InceptionI3d (tests/golden/make_golden_i3d.py): every end point, the pooled
+    features and the time-averaged logits of a 16-frame 224x224 clip (the evaluator's shape)."""
+    from oracle import i3d as oi
+    z, sd = i3d_fixture()
+    B, T, seed = z["x_a"].tolist()
+    x = torch.randn(B, 3, T, 224, 224, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        eps = {}
+        feats = oi.extract_features(x, sd, eps)
+        logits = oi.forward(x, sd)
+    for name, _, _ in oi.ENDPOINTS:
+        torch.testing.assert_close(eps[name][:, ::7, ::3, ::5, ::5], torch.from_numpy(z["ep_" + name]), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(feats, torch.from_numpy(z["features_a"]), atol=1e-4, rtol=1e-5)
+    torch.testing.assert_close(logits, torch.from_numpy(z["logits_a"]), atol=1e-4, rtol=1e-5)
+
+
+def test_i3d_state_dict_keys_are_the_references():
+    """The product module owns parameters under the reference's names, in the reference's order and shapes (a checkpoint made
+    for src/models/motionencoder/pytorch_i3d.py loads unchanged); host logic only, no GPU."""
+    import gsdd_amd
+    from src.models.motionencoder.pytorch_i3d import InceptionI3d
+    assert InceptionI3d is gsdd_amd.InceptionI3d
+    z, sd = i3d_fixture()
+    m = InceptionI3d()
+    assert list(m.state_dict().keys()) == [str(k) for k in z["keys"]]
+    m.load_state_dict(sd)                                                   # strict
+    with pytest.raises(gsdd_amd.GsddError):
+        m.eval()(torch.zeros(1, 3, 16, 224, 224))                           # no CPU fallback
