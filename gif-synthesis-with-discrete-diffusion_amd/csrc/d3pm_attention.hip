@@ -563,6 +563,8 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     // that was not flat after 384 keys seldom becomes flat): chunks 1, 6, 15, 32, ...
     bool adapt = false;
     int probe = 1, backoff = 4;
+    float kbj[4] = {0.f, 0.f, 0.f, 0.f};        // the bound's per-sub-tile numbers (wave-uniform values); 0 = clears nothing
+    int kb_next = 1, kb_gap = 1;                // chunk of the next recomputation, and the gap after it
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(c + 1);
@@ -579,33 +581,48 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
           if (attempt >= 0) {
             uint32_t thr2[4] = {0u, 0u, 0u, 0u};
             uint32_t skipmask[4] = {0u, 0u, 0u, 0u};
+            const uint32_t allmask = (1u << npairs) - 1u;
             if (PM >= 2 && c > 0) {
+                // The bound's per-sub-tile numbers kbj (kernel note) only grow along a row -- the row sum grows, and log2(row sum) + m
+                // does not change when m moves -- so a stale kbj stays a valid (only more cautious) bound: the masks of a chunk are four
+                // compares of its tile norms with the kbj in hand.  The expensive part (row sums through the LDS permute path, a
+                // logarithm, a row minimum: a serial latency chain of ~600 cycles per chunk that cost 8 % when it ran every chunk) is
+                // redone only when the stale numbers leave tiles uncleared, and then at doubling intervals (chunks 1, 2, 4, 8, ...): flat
+                // rows compute it once, rows it cannot help four times.
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // row sum of query li at the start of this chunk: accumulator column 12, row li = lane 16 (li >> 2) + 12, register li & 3
-                    const int src = ((li >> 2) << 4) + 12;
-                    const float r0 = __shfl(sav[j][0], src), r1 = __shfl(sav[j][1], src), r2 = __shfl(sav[j][2], src),
-                                r3 = __shfl(sav[j][3], src);
-                    const int rr = li & 3;
-                    const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
-                    // the bound (kernel note): per query the largest tile norm that still keeps every probability below 2^-PM of the
-                    // row sum; its minimum over the sub-tile's 16 queries (a DPP row) against the tile norms held by lanes 0..11.
-                    // 0.02 of slack in the exponent: v_log_f32 is good to 1 ulp of a value below 2^5 here.  A zero row sum gives
-                    // -inf, a NaN one NaN: fmaxf turns both into 0, "never cleared".
-                    float kbq = (__builtin_amdgcn_logf(rs) - (float)PM + mq[j] - 0.02f) * rqn[j];
-                    kbq = fmaxf(kbq, 0.f);
-                    const float kbj = row16_min(kbq);
-                    skipmask[j] = (uint32_t)__ballot(kn_cur < kbj);
-                    if (adapt) {
-                        // measured test: threshold of query li = 2^-PM * that row sum, as an f16 replicated in both halves.  A zero
-                        // row sum makes every tile take the lo half; an inf threshold (row sum beyond the f16 range) none.
-                        const _Float16 th = (_Float16)(rs * (1.0f / (float)(1 << PM)));
-                        const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, th);
-                        thr2[j] = hb | (hb << 16);
+                for (int j = 0; j < 4; ++j) skipmask[j] = (uint32_t)__ballot(kn_cur < kbj[j]);
+                const bool stale_clears = (skipmask[0] & skipmask[1] & skipmask[2] & skipmask[3] & allmask) == allmask;
+                const bool refresh = !stale_clears && c >= kb_next;
+                if (refresh) { kb_next = c + kb_gap; kb_gap *= 2; }
+                if (refresh || adapt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // row sum of query li at the start of this chunk: accumulator column 12, row li = lane 16 (li >> 2) + 12, register li & 3
+                        const int src = ((li >> 2) << 4) + 12;
+                        const float r0 = __shfl(sav[j][0], src), r1 = __shfl(sav[j][1], src), r2 = __shfl(sav[j][2], src),
+                                    r3 = __shfl(sav[j][3], src);
+                        const int rr = li & 3;
+                        const float rs = rr == 0 ? r0 : (rr == 1 ? r1 : (rr == 2 ? r2 : r3));
+                        if (refresh) {
+                            // per query the largest tile norm that still keeps every probability below 2^-PM of the row sum; its minimum
+                            // over the sub-tile's 16 queries (a DPP row; the four rows of a wave hold the same queries) against the tile
+                            // norms held by lanes 0..11.  0.02 of slack in the exponent: v_log_f32 is good to 1 ulp of a value below 2^5
+                            // here.  A zero row sum gives -inf, a NaN one NaN: fmaxf turns both into 0, "never cleared".
+                            float kbq = (__builtin_amdgcn_logf(rs) - (float)PM + mq[j] - 0.02f) * rqn[j];
+                            kbq = fmaxf(kbq, 0.f);
+                            kbj[j] = row16_min(kbq);
+                            skipmask[j] = (uint32_t)__ballot(kn_cur < kbj[j]);
+                        }
+                        if (adapt) {
+                            // measured test: threshold of query li = 2^-PM * that row sum, as an f16 replicated in both halves.  A zero
+                            // row sum makes every tile take the lo half; an inf threshold (row sum beyond the f16 range) none.
+                            const _Float16 th = (_Float16)(rs * (1.0f / (float)(1 << PM)));
+                            const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, th);
+                            thr2[j] = hb | (hb << 16);
+                        }
                     }
                 }
             }
-            const uint32_t allmask = (1u << npairs) - 1u;
             const uint32_t clr_all = skipmask[0] & skipmask[1] & skipmask[2] & skipmask[3] & allmask;
             int ncleared = 0;
 #pragma unroll

@@ -122,7 +122,7 @@ class VQVAETrainer:
                                        n_local=n_local, m_local=z.shape[0])
         self.last_perplexity = scal[1]                      # of this rank's latents (videogpt_vq_vae.py:218-219)
         emb_st = ((zq - z) + z).contiguous()
-        sv["z"], sv["zq"], sv["emb_st"] = z, zq, emb_st
+        sv["z"], sv["zq"], sv["emb_st"], sv["idx"] = z, zq, emb_st, idx
         hp = ops.gemm(emb_st, p["post_w"], torch.empty((z.shape[0], vq.n_hiddens), **f), in_dims=dims, out_grid=dims[1:],
                       epi_shift=p["post_b"])
         r, pro, mr, sv["dec_res"] = self._res_stack_fwd(hp, dims, p["dec_res"], vq.decoder.res_stack)

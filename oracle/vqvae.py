@@ -253,5 +253,5 @@ def forward_train(x, sd, cfg, perm, init_perm=None, init_noise=None, noise=None)
     avg = onehot.mean(dim=0)
     perplexity = torch.exp(-torch.sum(avg * torch.log(avg + 1e-10)))
     out = {"pred_data": h, "gt_data": x, "losses": {"recon_loss": F.mse_loss(h, x) / 0.06, "commitment_loss": commitment},
-           "perplexity": perplexity, "encodings": idx}
+           "perplexity": perplexity, "encodings": idx, "z": z}
     return out, new

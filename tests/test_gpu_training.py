@@ -67,6 +67,54 @@ def test_loss_gradients_match_autograd_of_oracle(G, golden, tvals):
     print("worst relative gradient error:", worst)
 
 
+def test_loss_gradients_full_size_two_layers(G):
+    """Gradient parity at the workload's own sequence and class counts (L = 4096 tokens, K = 4096 codes, one clip, TWO of the 19
+    layers: the oracle's autograd keeps 16 x 4096^2 scores per layer): every parameter gradient against torch.autograd of the CPU
+    oracle, same bar as the fixture-sized test.  Weights of a trained-like magnitude, so that the softmax rows are not flat."""
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    from oracle import d3pm as od
+    from tests.conftest import parity_report
+    torch.manual_seed(7)
+    cfg = dict(K=4096, L=4096, spatial=[64, 64], n_layer=2, cond_dim=512, T=100, guidance=2, B=1)
+    d = G.DalleMaskImageEmbedding(num_embed=cfg["K"], spatial_size=cfg["spatial"], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=cfg["L"], block_activate="GELU2",
+                                 content_spatial_size=cfg["spatial"], condition_dim=512, diffusion_step=100)
+    g = torch.Generator().manual_seed(8)
+    for mod in tr.modules():
+        if isinstance(mod, torch.nn.Linear):
+            mod.weight.data = torch.randn(mod.weight.shape, generator=g) * (1.0 / mod.in_features ** 0.5)
+            mod.bias.data = 0.1 * torch.randn(mod.bias.shape, generator=g)
+        elif isinstance(mod, torch.nn.Embedding):
+            mod.weight.data = torch.randn(mod.weight.shape, generator=g) * 0.5
+    dm = G.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", auxiliary_loss_weight=5e-4,
+                                adaptive_auxiliary_loss=True, guidance_scale=2, content_seq_len=cfg["L"])
+    sd = {k: v.detach().clone() for k, v in dm.state_dict().items()}
+    x0 = torch.randint(0, cfg["K"], (1, cfg["L"]), generator=g)
+    cond = torch.randn(1, 1, 512, generator=g)
+    t = torch.tensor([41], dtype=torch.long)
+    pt = torch.ones(1) / 100
+    leaf = {k: (v.clone().requires_grad_(True) if k.startswith("transformer.") and v.dtype.is_floating_point else v) for k, v in sd.items()}
+    want_loss, _, _, _ = od.train_loss(x0, cond, t, pt, leaf, 21, 0)
+    want_loss.backward()
+    want = {k[len("transformer."):]: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()
+            if k.startswith("transformer.") and v.dtype.is_floating_point}
+    dm = dm.cuda()
+    dm.set_noise(21, stream=0)
+    loss, got = D3PMTrainer(dm).loss_and_grads(x0.cuda(), cond.cuda(), t=t.cuda(), pt=pt.cuda())
+    np.testing.assert_allclose(loss.item(), want_loss.item(), rtol=2e-5)
+    assert set(got) == set(want), set(got) ^ set(want)
+    gmax = max(w.abs().max().item() for w in want.values())
+    worst = ("", 0.0)
+    for k, w in want.items():
+        scale = max(w.abs().max().item(), 1e-3 * gmax)
+        err = (got[k].cpu() - w).abs().max().item() / scale
+        if err > worst[1]:
+            worst = (k, err)
+    parity_report("d3pm_full_size_two_layer_gradients", {"parameters": len(want), "worst_relative_error": worst[1], "worst_parameter": worst[0],
+                                                         "loss": loss.item(), "oracle_loss": want_loss.item()})
+    assert worst[1] < 2e-3, worst
+
+
 def test_adam_step_matches_torch(G, golden):
     from gsdd_amd.d3pm_train import D3PMTrainer
     sd, a, cfg = golden("d3pm_L64")

@@ -56,11 +56,13 @@ def case(G, golden, name):
         m = G.VQVAE(None, 128, 4096, 256, 3, [1, 8, 8], 16, 128)
         sd = {k: v.clone() for k, v in m.state_dict().items()}
         x = torch.randn(1, 3, 16, 128, 128)
-        # a codebook spread over this clip's own latents (a random one maps every latent to one code), as the data-dependent init does
+        # a codebook spread over this clip's own train-mode latents (a random one maps every latent to one code), as the data-dependent
+        # init does; every latent's nearest code is its own jittered copy, far from a tie
         from oracle import vqvae as ov
+        perm0 = np.random.default_rng(5).permutation(4096)
         with torch.no_grad():
-            m_eval = {k: v.clone() for k, v in sd.items()}
-            flat = ov.pre_vq(x, m_eval, cfg).permute(0, 2, 3, 4, 1).reshape(-1, 128)
+            o0, _ = ov.forward_train(x, {k: v.clone() for k, v in sd.items()}, cfg, perm0)
+            flat = o0["z"].permute(0, 2, 3, 4, 1).reshape(-1, 128)
         sd["codebook.embeddings"] = flat + 0.05 * torch.randn(4096, 128)
         sd["codebook.z_avg"] = sd["codebook.embeddings"].clone()
         sd["codebook.N"] = torch.ones(4096)
@@ -93,38 +95,56 @@ def case(G, golden, name):
 def compare(got, want, tol=2e-3):
     assert set(got) == set(want), set(got) ^ set(want)
     gmax = max(w.abs().max().item() for w in want.values())
-    worst = ("", 0.0)
+    errs = {}
     for k, w in want.items():
         gk = got[k].detach().cpu()
         assert gk.shape == w.shape, (k, gk.shape, w.shape)
         # per-channel constants in front of a train-mode BatchNorm (conv_last bias, the last block's fc biases) have a
         # mathematically zero gradient: both sides are rounding noise there, hence the floor
         scale = max(w.abs().max().item(), 1e-3 * gmax)
-        err = (gk - w).abs().max().item() / scale
-        if err > worst[1]:
-            worst = (k, err)
-        assert err < tol, f"{k}: relative max error {err:.3e} (|g|max {scale:.3e})"
-    print("worst relative gradient error:", worst)
-    return worst
+        errs[k] = (gk - w).abs().max().item() / scale
+    order = sorted(errs, key=errs.get, reverse=True)
+    print("worst relative gradient errors:", [(k, f"{errs[k]:.2e}") for k in order[:6]])
+    bad = [(k, f"{errs[k]:.3e}") for k in order if not errs[k] < tol]
+    assert not bad, f"relative max error over {tol}: {bad[:8]} ({len(bad)} of {len(errs)} tensors)"
+    return order[0], errs[order[0]]
 
 
 @pytest.mark.parametrize("name", ["train_ds188", "ds244", "wide", "ds444", "c128", "full"])
 def test_vqvae_gradients_match_autograd_of_oracle(G, golden, name):
     """`full`: C2's own model on one 16x128x128 clip -- every parameter gradient of the 28.9 M-parameter model against autograd of
-    the CPU oracle (same bar as the small cases: relative max error < 2e-3 of the tensor's largest gradient)."""
+    the CPU oracle run in fp64 (same bar as the small cases: relative max error < 2e-3 of the tensor's largest gradient)."""
     from gsdd_amd.vqvae_trainer import VQVAETrainer
     x, sd, cfg, perm = case(G, golden, name)
     out, want = oracle_grads(x, sd, cfg, perm)
+    want32 = None
+    if name == "full":
+        # At this size the f32 oracle is not the truth any more: its weight gradients are f32 sums over up to 1e6 positions with heavy
+        # cancellation, and against an fp64 run of the same oracle they are off by up to 2.5e-2 of a tensor's largest entry (measured;
+        # recorded below).  The fp64 run (same code, double tensors, ~20 s) is the reference here.
+        want32 = want
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        out64, want = oracle_grads(x.double(), sd64, cfg, perm)
+        assert torch.equal(out64["encodings"], out["encodings"])
+        want = {k: v.float() for k, v in want.items()}
     m = build_vqvae(G, sd, cfg)
     pt = torch.from_numpy(np.asarray(perm))
     m.perm_source = lambda n: pt
-    losses, got = VQVAETrainer(m).loss_and_grads(x.cuda())
+    trainer = VQVAETrainer(m)
+    sv, losses = trainer.forward(x.cuda())
+    got = trainer.backward(sv)
+    code_mismatches = int((sv["idx"].cpu() != out["encodings"].reshape(-1)).sum())
+    if name == "full":
+        assert code_mismatches == 0, f"{code_mismatches} code indices differ from the oracle's: the gradients are not comparable"
     np.testing.assert_allclose(losses["recon_loss"].item(), out["losses"]["recon_loss"].item(), rtol=1e-4)
     np.testing.assert_allclose(losses["commitment_loss"].item(), out["losses"]["commitment_loss"].item(), rtol=1e-4)
     worst = compare(got, want)
     if name == "full":
         from tests.conftest import parity_report
-        parity_report("vqvae_full_size_gradients", {"parameters": len(want), "worst_relative_error": worst[1], "worst_parameter": worst[0],
+        gmax = max(w.abs().max().item() for w in want.values())
+        o32 = max(((want32[k] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), k) for k, w in want.items())
+        parity_report("vqvae_full_size_gradients", {"parameters": len(want), "reference": "fp64 run of the CPU oracle", "worst_relative_error": worst[1],
+                                                    "worst_parameter": worst[0], "f32_oracle_vs_fp64_worst": o32[0], "f32_oracle_vs_fp64_worst_parameter": o32[1],
                                                     "recon_loss": losses["recon_loss"].item(), "oracle_recon_loss": out["losses"]["recon_loss"].item()})
 
 
