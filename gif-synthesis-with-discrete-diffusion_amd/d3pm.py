@@ -675,10 +675,10 @@ class DiscreteDiffusion(nn.Module):
         and the sampler are not differentiable in the reference either (arg-min / arg-max cut the graph) and run under no_grad."""
         dev = autoencoder.device
         x = batch["video"].to(dev)
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # data parallel: this rank's clips are rows rank*B.. of the global batch, so the ranks draw different noise
-            self.diffusion_model.row_offset = dist.get_rank() * x.shape[0]
+        from .parallel import broadcast_buffers, set_rank_noise_rows
+        set_rank_noise_rows(self.diffusion_model, x.shape[0])          # data parallel: the ranks draw different noise rows
+        if self.diffusion_model.training:
+            broadcast_buffers(self.diffusion_model)                    # DDP's per-forward buffer broadcast (Lt_history / Lt_count)
         with torch.no_grad():
             quant = autoencoder.encode(x)
         quant_flat = quant.view(x.shape[0], -1)

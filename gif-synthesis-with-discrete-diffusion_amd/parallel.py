@@ -68,6 +68,25 @@ def broadcast_module(module, src=0):
             m._packed = None
 
 
+@torch.no_grad()
+def broadcast_buffers(module, src=0):
+    """Rank `src`'s buffers to every rank -- what DistributedDataParallel(broadcast_buffers=True, the default the reference trains
+    under) does at the start of every forward: the D3PM importance-sampling statistics `Lt_history` / `Lt_count`
+    (diffusion_transformer.py:425-433) are rank 0's on every rank, so all ranks draw timesteps from the same distribution."""
+    if world_size() == 1:
+        return
+    for t in module.buffers():
+        if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+            dist.broadcast(t.data, src)
+
+
+def set_rank_noise_rows(diffusion_model, local_batch):
+    """Data parallel: this rank's clips are rows rank * B .. of the global batch, so the ranks draw different q_sample / Gumbel noise
+    rows and a world-size-N step equals the single-process step on the concatenated batch."""
+    if world_size() > 1:
+        diffusion_model.row_offset = dist.get_rank() * int(local_batch)
+
+
 def assert_same_parameters(module, what="parameters"):
     """Cheap drift check: the fp64 sum of all parameters must agree across ranks."""
     if world_size() == 1:

@@ -55,6 +55,13 @@ class ClipFolderDataModule:
         self.batch_size, self.device, self.shuffle_seed = batch_size, device, shuffle_seed
         self.sequence_length, self.resolution = sequence_length, resolution
         self.epoch = 0
+        self.shard = (0, 1)
+
+    def set_shard(self, rank, world):
+        """Data parallel: this process reads, decodes and preprocesses only batches rank, rank + world, ... of every split (whole
+        rounds: a trailing round that cannot serve every rank is dropped, all ranks take the same number of steps) -- the role of
+        the reference's DistributedSampler.  The order is the single-process order, so N ranks see the same global batches."""
+        self.shard = (int(rank), int(world))
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)                          # the shuffle is a function of (shuffle_seed, epoch)
@@ -65,7 +72,10 @@ class ClipFolderDataModule:
         order = list(range(len(ds)))
         if shuffle:
             order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(self.shuffle_seed + self.epoch)).tolist()
-        for i in range(0, len(order), self.batch_size):
+        rank, world = self.shard
+        nbatch = (len(order) + self.batch_size - 1) // self.batch_size
+        for b in range(rank, (nbatch // world) * world, world):
+            i = b * self.batch_size
             items = [ds[j] for j in order[i:i + self.batch_size]]
             video = torch.stack([preprocess(it["frames"].to(self.device), self.resolution) for it in items])   # (B,3,T,R,R)
             yield {"video": video, "text": [it["text"] for it in items], "length": [video.shape[1]] * len(items),

@@ -80,10 +80,14 @@ class MultistageTextMotionModel(BaseModel):
         if self._native is None:
             self._native = D3PMTrainer(self.generator.diffusion_model, lr=self.lr_args.get("gen_lr", 1e-4))
             self._native.load_optimizer_state(getattr(self, "_native_state", None))
+        from gsdd_amd.parallel import broadcast_buffers, set_rank_noise_rows
         with torch.no_grad():
             x = batch["video"].to(self.autoencoder.device)
             tokens = self.autoencoder.encode(x).view(x.shape[0], -1)
             text_emb = self.generator._text(batch["text"], tokens.device)
+        # as the glue does on the reference-shaped path: per-rank noise rows, rank 0's importance-sampling statistics everywhere
+        set_rank_noise_rows(self.generator.diffusion_model, x.shape[0])
+        broadcast_buffers(self.generator.diffusion_model)
         loss = self._native.step(tokens, text_emb)[0]
         self.generator_losses["train"].update({"losses": loss})
         self.loss_dict["generator_loss"] = loss

@@ -34,6 +34,7 @@ class Trainer:
         self.best_model_path, self.best_score = "", None
         self.log_dir = default_root_dir
         self.datamodule = None
+        self._dm_sharded = False
         self.rank, self.world = init_distributed()
 
     # ------------------------------------------------------------------ plumbing
@@ -49,7 +50,15 @@ class Trainer:
 
     def _batches(self, loader):
         """Batches are dealt round-robin to the ranks, in whole rounds: a trailing round that cannot serve every rank is dropped,
-        so all ranks take the same number of steps (every step holds collectives)."""
+        so all ranks take the same number of steps (every step holds collectives).  A datamodule that shards by itself
+        (`set_shard(rank, world)`: this rank only reads and preprocesses its own batches, like a DistributedSampler) hands over
+        exactly those batches; any other iterable is dealt here, every rank walking all of it."""
+        if self._dm_sharded:
+            for i, batch in enumerate(loader):
+                if self.limit_batches is not None and i >= self.limit_batches:
+                    break
+                yield i, batch
+            return
         mine = None
         for i, batch in enumerate(loader):
             if self.limit_batches is not None and i >= self.limit_batches * self.world:
@@ -63,12 +72,13 @@ class Trainer:
     def _attach(self, model, datamodule):
         model.trainer = self
         self.datamodule = datamodule
+        self._dm_sharded = False
+        if hasattr(datamodule, "set_shard"):
+            datamodule.set_shard(self.rank, self.world)
+            self._dm_sharded = True
         if self.world > 1:
-            for m in model.modules():                                         # per-rank noise rows (global row key)
-                if hasattr(m, "row_offset") and hasattr(m, "set_noise"):
-                    m.rank_stride = (self.rank, self.world)
             from gsdd_amd.parallel import broadcast_module
-            broadcast_module(model)
+            broadcast_module(model)                                           # (per-rank noise rows: parallel.set_rank_noise_rows, per step)
 
     # ------------------------------------------------------------------ checkpoints
     def _checkpoint(self, model):

@@ -92,21 +92,29 @@ def case(G, golden, name):
     return x, sd, cfg, np.random.default_rng(5).permutation(nperm)
 
 
-def compare(got, want, tol=2e-3):
+def rel_errors(got, want):
+    """Per tensor: max |got - want| over the tensor's largest |want| (floored at 1e-3 of the model's largest gradient: per-channel
+    constants in front of a train-mode BatchNorm -- conv_last bias, the last block's fc biases -- have a mathematically zero
+    gradient, both sides are rounding noise there)."""
     assert set(got) == set(want), set(got) ^ set(want)
     gmax = max(w.abs().max().item() for w in want.values())
     errs = {}
     for k, w in want.items():
         gk = got[k].detach().cpu()
         assert gk.shape == w.shape, (k, gk.shape, w.shape)
-        # per-channel constants in front of a train-mode BatchNorm (conv_last bias, the last block's fc biases) have a
-        # mathematically zero gradient: both sides are rounding noise there, hence the floor
-        scale = max(w.abs().max().item(), 1e-3 * gmax)
-        errs[k] = (gk - w).abs().max().item() / scale
+        errs[k] = (gk - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax)
+    return errs
+
+
+def compare(got, want, tol=2e-3, floor=None):
+    """floor: optional per-tensor error of an f32 reference implementation against the same `want` (see the full-size case): a tensor
+    may then be off by twice that, where that is more than `tol`."""
+    errs = rel_errors(got, want)
     order = sorted(errs, key=errs.get, reverse=True)
     print("worst relative gradient errors:", [(k, f"{errs[k]:.2e}") for k in order[:6]])
-    bad = [(k, f"{errs[k]:.3e}") for k in order if not errs[k] < tol]
-    assert not bad, f"relative max error over {tol}: {bad[:8]} ({len(bad)} of {len(errs)} tensors)"
+    lim = lambda k: tol if floor is None else max(tol, 2.0 * floor[k])
+    bad = [(k, f"{errs[k]:.3e} > {lim(k):.3e}") for k in order if not errs[k] < lim(k)]
+    assert not bad, f"relative max error over the limit: {bad[:8]} ({len(bad)} of {len(errs)} tensors)"
     return order[0], errs[order[0]]
 
 
@@ -119,9 +127,12 @@ def test_vqvae_gradients_match_autograd_of_oracle(G, golden, name):
     out, want = oracle_grads(x, sd, cfg, perm)
     want32 = None
     if name == "full":
-        # At this size the f32 oracle is not the truth any more: its weight gradients are f32 sums over up to 1e6 positions with heavy
-        # cancellation, and against an fp64 run of the same oracle they are off by up to 2.5e-2 of a tensor's largest entry (measured;
-        # recorded below).  The fp64 run (same code, double tensors, ~20 s) is the reference here.
+        # At this size f32 is not the truth any more.  The weight gradients are sums over up to 1e6 positions of dY * X in which the
+        # per-channel mean of dY is mathematically zero behind a train-mode BatchNorm while X (post-ReLU) has a large mean: the sum
+        # cancels to a small fraction of its terms, and ANY f32 evaluation carries the rounding noise of the cancelled part.  Against
+        # an fp64 run of the same oracle, the f32 oracle (torch-CPU autograd) is off by up to 2.5e-2 of a tensor's largest entry --
+        # in the same tensors, by the same amounts, as the HIP path.  So the reference is the fp64 run (same code, double tensors,
+        # ~20 s), and a tensor may deviate from it by 2e-3 or by twice what torch's own f32 autograd deviates, whichever is larger.
         want32 = want
         sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
         out64, want = oracle_grads(x.double(), sd64, cfg, perm)
@@ -138,14 +149,19 @@ def test_vqvae_gradients_match_autograd_of_oracle(G, golden, name):
         assert code_mismatches == 0, f"{code_mismatches} code indices differ from the oracle's: the gradients are not comparable"
     np.testing.assert_allclose(losses["recon_loss"].item(), out["losses"]["recon_loss"].item(), rtol=1e-4)
     np.testing.assert_allclose(losses["commitment_loss"].item(), out["losses"]["commitment_loss"].item(), rtol=1e-4)
-    worst = compare(got, want)
-    if name == "full":
+    if name != "full":
+        compare(got, want)
+    else:
         from tests.conftest import parity_report
-        gmax = max(w.abs().max().item() for w in want.values())
-        o32 = max(((want32[k] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), k) for k, w in want.items())
-        parity_report("vqvae_full_size_gradients", {"parameters": len(want), "reference": "fp64 run of the CPU oracle", "worst_relative_error": worst[1],
-                                                    "worst_parameter": worst[0], "f32_oracle_vs_fp64_worst": o32[0], "f32_oracle_vs_fp64_worst_parameter": o32[1],
+        e32 = rel_errors(want32, want)
+        ehip = rel_errors(got, want)
+        k32, khip = max(e32, key=e32.get), max(ehip, key=ehip.get)
+        parity_report("vqvae_full_size_gradients", {"parameters": len(want), "reference": "fp64 run of the CPU oracle", "worst_relative_error": ehip[khip],
+                                                    "worst_parameter": khip, "f32_oracle_vs_fp64_worst": e32[k32], "f32_oracle_vs_fp64_worst_parameter": k32,
+                                                    "tensors_over_2e-3": {"hip": sum(v >= 2e-3 for v in ehip.values()), "f32_oracle": sum(v >= 2e-3 for v in e32.values())},
+                                                    "median_relative_error": {"hip": sorted(ehip.values())[len(ehip) // 2], "f32_oracle": sorted(e32.values())[len(e32) // 2]},
                                                     "recon_loss": losses["recon_loss"].item(), "oracle_recon_loss": out["losses"]["recon_loss"].item()})
+        compare(got, want, floor=e32)
 
 
 def test_vqvae_forward_backward_through_autograd_bridge(G, golden):

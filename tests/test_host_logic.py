@@ -351,3 +351,37 @@ def test_convT_phases_reproduce_conv_transpose(k, s):
                 if 0 <= i < n_in:
                     got[oc * s + p] += w[kk] * x[i]
     np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_clip_folder_datamodule_shards_whole_rounds(tmp_path, monkeypatch):
+    """set_shard(rank, world): every rank reads only its own batches (b = rank, rank + world, ...), all ranks take the same number of
+    steps (a trailing round that cannot serve every rank is dropped), and together they cover the single-process order."""
+    import numpy as np
+    import src  # noqa: F401
+    import gsdd_amd.data
+    from src.datamodules.clip_folder_datamodule import ClipFolderDataModule
+    rng = np.random.default_rng(0)
+    for c in ("a", "b"):
+        os.makedirs(tmp_path / "train" / c)
+        for i in range(5):
+            clip = rng.integers(0, 255, (4, 8, 8, 3), dtype=np.uint8)
+            clip[0, 0, 0, 0] = len(os.listdir(tmp_path / "train" / c)) + (100 if c == "b" else 0)      # a recognisable first byte
+            np.save(tmp_path / "train" / c / f"clip{i}.npy", clip)
+    reads = []
+    monkeypatch.setattr(gsdd_amd.data, "preprocess", lambda frames, res: (reads.append(int(frames[0, 0, 0, 0])), frames.float().permute(3, 0, 1, 2))[1])
+
+    def batches(rank, world):
+        dm = ClipFolderDataModule(str(tmp_path), sequence_length=4, resolution=8, batch_size=2, device="cpu", shuffle_seed=3)
+        dm.set_shard(rank, world)
+        reads.clear()
+        out = [[int(v[0, 0, 0, 0]) for v in b["video"]] for b in dm.train_dataloader()]
+        return out, list(reads)
+    single, _ = batches(0, 1)                        # 10 clips, batch 2 -> 5 batches
+    assert len(single) == 5
+    for world in (2, 3):
+        per_rank = [batches(r, world) for r in range(world)]
+        rounds = 5 // world
+        assert all(len(b) == rounds for b, _ in per_rank)
+        for r, (b, read) in enumerate(per_rank):
+            assert b == [single[i * world + r] for i in range(rounds)]
+            assert len(read) == 2 * rounds            # only its own clips were read and preprocessed
