@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsdd.so")
+LIB_PATH = os.environ.get("GSDD_LIB_PATH") or os.path.join(_HERE, "libgsdd.so")     # (the override: A/B runs of two builds)
 _lib = None
 
 EXPORTS = [

@@ -460,8 +460,7 @@ template <int KC4, int PM = 1>
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
                                                                 const uint4* __restrict__ vp, const float* __restrict__ knorm,
                                                                 int B, int L, int H, float* __restrict__ out,
-                                                                float* __restrict__ lse, unsigned long long* __restrict__ redo,
-                                                                int dbg) {          // dbg (GSDD_ATTN_DBG): 1 no measured test, 2 no bound
+                                                                float* __restrict__ lse, unsigned long long* __restrict__ redo) {
     __shared__ AttnSmem4<KC4> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqb = (L + 255) / 256;
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < 4; ++j) skipmask[j] = (uint32_t)__ballot(kn_cur < kbj[j]);
                 const bool stale_clears = (skipmask[0] & skipmask[1] & skipmask[2] & skipmask[3] & allmask) == allmask;
-                const bool refresh = !stale_clears && c >= kb_next && !(dbg & 2);
+                const bool refresh = !stale_clears && c >= kb_next;
                 if (refresh) { kb_next = c + kb_gap; kb_gap *= 2; }
                 if (refresh || adapt) {
 #pragma unroll
@@ -648,7 +647,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
                 if (PM >= 2 && !cleared) {                               // (a cleared chunk says nothing about the measured test)
                     if (adapt) {
                         if (2 * skipped < 4 * npairs) { adapt = false; probe = backoff; backoff *= 2; }
-                    } else if (--probe <= 0 && !(dbg & 1)) {
+                    } else if (--probe <= 0) {
                         adapt = true;
                     }
                 }
@@ -793,13 +792,11 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
         const int pmode = attn_p_mode(L);
         float* nolse = nullptr;
-        const char* dbge = getenv("GSDD_ATTN_DBG");                  // timing experiments: switch the adaptive mode's two tests off
-        const int dbg = dbge != nullptr ? atoi(dbge) : 0;
-        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo, dbg);
-        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo, dbg);
-        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo, dbg);
-        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo, dbg);
-        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo, dbg);
+        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
     } else {
         hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);      // (never redoes a chunk)
     }
@@ -828,10 +825,10 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     const char* tp = getenv("GSDD_ATTN_TRAIN_P");
     if (tp != nullptr && tp[0] == 'a' && L >= 2048)
         hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
-                           B, L, H, out, lse, noredo, 0);
+                           B, L, H, out, lse, noredo);
     else
         hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
-                           B, L, H, out, lse, noredo, 0);
+                           B, L, H, out, lse, noredo);
     GSDD_CHECK_LAUNCH();
     *done = 1;
     return GSDD_OK;

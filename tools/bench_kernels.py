@@ -25,6 +25,13 @@ def timeit(fn, iters=10, warm=2):
 def main():
     which = sys.argv[1:] or ["attn", "gemm", "layer", "logits", "step"]
     dev = "cuda"
+    # the first measurement of a process otherwise runs at the idle clock: the power state takes far longer than timeit's two warm
+    # calls to ramp up (measured: the same kernel 1.14 ms as the first case of a run, 0.98 ms as the third)
+    wa = torch.randn((8192, 8192), device=dev)
+    for _ in range(60):
+        wa = (wa @ wa).clamp_(-1, 1)
+    torch.cuda.synchronize()
+    del wa
     B2, L, H, D, K = 32, 4096, 16, 64, 4096
     M = B2 * L
     if "attn" in which:
