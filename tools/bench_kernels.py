@@ -216,7 +216,7 @@ def main():
             del logits
 
     if "nearest" in which:
-        for Mn in (32768, 262144):                     # C2 at bs 8 (one encode of the bench's decode batch) and at bs 64
+        for Mn in [int(v) for v in os.environ.get("GSDD_NEAREST_M", "32768,262144").split(",")]:    # C2 at bs 8 and at bs 64
             z = torch.randn((Mn, 128), device=dev)
             cb = torch.randn((4096, 128), device=dev)
             idx = torch.empty((Mn,), dtype=torch.int64, device=dev)
