@@ -15,7 +15,7 @@ EXPORTS = [
     "gsdd_axial_attention", "gsdd_pool3d", "gsdd_nearest_code", "gsdd_nearest_code_workspace_bytes", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
     "gsdd_codebook_ema", "gsdd_code_perplexity", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
-    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_layer_pack", "gsdd_d3pm_layer_pack_h2", "gsdd_rows_linear_pack_many", "gsdd_rows_linear", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_gelu2", "gsdd_ln_fwd", "gsdd_ln_bwd", "gsdd_wgrad",
+    "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_layer_pack", "gsdd_d3pm_layer_pack_h2", "gsdd_rows_linear_pack_many", "gsdd_rows_linear", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_d3pm_train_loss_grad", "gsdd_gelu2", "gsdd_ln_fwd", "gsdd_ln_bwd", "gsdd_wgrad",
     "gsdd_batch_rowsum", "gsdd_colsum", "gsdd_d3pm_attention_train", "gsdd_d3pm_attention_bwd", "gsdd_d3pm_attention_bwd_workspace_bytes", "gsdd_d3pm_embed_bwd", "gsdd_small_linear_bwd",
     "gsdd_adaln_bwd", "gsdd_adam", "gsdd_adam_multi", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
@@ -121,6 +121,7 @@ def lib():
         L.gsdd_d3pm_q_sample.argtypes = [_p, _p, _i, _i, _i, _i, C.POINTER(_p), _p, C.c_uint64, _p, _i64, _p]
         L.gsdd_d3pm_train_loss.argtypes = [C.POINTER(TrainDesc), _p]
         L.gsdd_d3pm_train_loss_bwd.argtypes = [C.POINTER(TrainDesc), _p, _p]
+        L.gsdd_d3pm_train_loss_grad.argtypes = [C.POINTER(TrainDesc), _p, _p]
         L.gsdd_gelu2.argtypes = [_p, _p, _p, _i64, _i, _p]
         L.gsdd_ln_fwd.argtypes = [_p, _i64, _i, C.c_float, _p, _p, _p, _i, _i, _p, _p, _p]
         L.gsdd_ln_bwd.argtypes = [_p, _p, _p, _p, _p, _i, _i, _i64, _i, _p, _p, _p, _p, _i, _i, _p]

@@ -565,6 +565,20 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     int probe = 1, backoff = 4;
     float kbj[4] = {0.f, 0.f, 0.f, 0.f};        // the bound's per-sub-tile numbers (wave-uniform values); 0 = clears nothing
     int kb_next = 1, kb_gap = 1;                // chunk of the next recomputation, and the gap after it
+    if (PM >= 2) {
+        // A priori form of the bound, before any key has been seen: the FINAL row sum of query q is at least L * 2^(-||q'|| KNmax - m)
+        // (every score is at least -||q'|| ||k||; KNmax = the largest tile norm of this (b, h)), and the error budget is relative to the
+        // final row sum, so a tile whose probabilities stay below 2^-PM of that lower bound may take the hi half only:
+        //     ||q'|| knorm[u] - m < log2(L) - PM - ||q'|| KNmax - m   <=>   knorm[u] < (log2(L) - PM - slack) / ||q'|| - KNmax.
+        // With near-flat rows (||q'|| ||k|| << log2(L) - PM = 4 at L = 4096) this clears every tile of every chunk, the first included,
+        // and the running-sum form below never has to be computed.
+        float knm = 0.f;
+        for (int i = lane; i < (L >> 5); i += 64) knm = fmaxf(knm, knh[i]);
+        knm = wave_max(knm) * 1.0001f;
+        const float budget = log2f((float)L) - (float)PM - 0.02f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kbj[j] = row16_min(fmaxf(budget * rqn[j] - knm, 0.f));
+    }
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(c + 1);
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
             uint32_t thr2[4] = {0u, 0u, 0u, 0u};
             uint32_t skipmask[4] = {0u, 0u, 0u, 0u};
             const uint32_t allmask = (1u << npairs) - 1u;
-            if (PM >= 2 && c > 0) {
+            if (PM >= 2) {
                 // The bound's per-sub-tile numbers kbj (kernel note) only grow along a row -- the row sum grows, and log2(row sum) + m
                 // does not change when m moves -- so a stale kbj stays a valid (only more cautious) bound: the masks of a chunk are four
                 // compares of its tile norms with the kbj in hand.  The expensive part (row sums through the LDS permute path, a
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
 #pragma unroll
                 for (int j = 0; j < 4; ++j) skipmask[j] = (uint32_t)__ballot(kn_cur < kbj[j]);
                 const bool stale_clears = (skipmask[0] & skipmask[1] & skipmask[2] & skipmask[3] & allmask) == allmask;
-                const bool refresh = !stale_clears && c >= kb_next;
+                const bool refresh = !stale_clears && c >= kb_next;         // (kb_next >= 1: the first chunk has no row sum yet)
                 if (refresh) { kb_next = c + kb_gap; kb_gap *= 2; }
                 if (refresh || adapt) {
 #pragma unroll
@@ -610,7 +624,8 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
                             // here.  A zero row sum gives -inf, a NaN one NaN: fmaxf turns both into 0, "never cleared".
                             float kbq = (__builtin_amdgcn_logf(rs) - (float)PM + mq[j] - 0.02f) * rqn[j];
                             kbq = fmaxf(kbq, 0.f);
-                            kbj[j] = row16_min(kbq);
+                            kbj[j] = fmaxf(kbj[j], row16_min(kbq));             // never below the a priori number
+
                             skipmask[j] = (uint32_t)__ballot(kn_cur < kbj[j]);
                         }
                         if (adapt) {

@@ -183,10 +183,13 @@ class D3PMTrainer:
         sv = self._forward(xt, cond, t)
         kw = dict(K=K, T=T, mask_weight=dm.mask_weight, aux_weight=dm.auxiliary_loss_weight,
                   adaptive_aux=dm.adaptive_auxiliary_loss)
-        fwd = ops.d3pm_train_loss(sv["logits"], x0, xt, t, pt, sched, dm.Lt_history, dm.Lt_count, want_probs=want_probs, **kw)
+        if want_probs or os.environ.get("GSDD_TRAIN_LOSS_SPLIT"):      # (the switch: A/B and the equality test of the two paths)
+            fwd = ops.d3pm_train_loss(sv["logits"], x0, xt, t, pt, sched, dm.Lt_history, dm.Lt_count, want_probs=want_probs, **kw)
+            dlogits = ops.d3pm_train_loss_bwd(sv["logits"], x0, xt, t, pt, sched, **kw)
+        else:                                                          # one pass over the logits for the loss and its gradient
+            fwd, dlogits = ops.d3pm_train_loss_grad(sv["logits"], x0, xt, t, pt, sched, dm.Lt_history, dm.Lt_count, **kw)
         fwd["t"], fwd["xt"] = t, xt
         self.last_fwd = fwd
-        dlogits = ops.d3pm_train_loss_bwd(sv["logits"], x0, xt, t, pt, sched, **kw)
 
         g = {}
         if getattr(self, "_arena", None) is None:

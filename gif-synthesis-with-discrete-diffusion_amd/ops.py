@@ -309,6 +309,32 @@ def d3pm_train_loss(logits, x0, xt, t_dev, pt, sched, Lt_history, Lt_count, *, K
     return out
 
 
+def d3pm_train_loss_grad(logits, x0, xt, t_dev, pt, sched, Lt_history, Lt_count, *, K, T, mask_weight, aux_weight, adaptive_aux,
+                         stream=None):
+    """d3pm_train_loss (without probs) and d3pm_train_loss_bwd in one pass over the logits -> (forward dict, dlogits)."""
+    B, L = x0.shape
+    dev = x0.device
+    f = dict(dtype=torch.float32, device=dev)
+    out = {"loss": torch.empty((1,), **f), "per_sample": torch.empty((B, 4), **f),
+           "x0_recon": torch.empty((B, L), dtype=torch.int64, device=dev),
+           "xt1_recon": torch.empty((B, L), dtype=torch.int64, device=dev), "probs": None}
+    scratch = torch.empty((3, B * L), **f)
+    d = TrainDesc()
+    d.logits, d.x0, d.xt, d.t_dev, d.pt = ptr(logits), ptr(x0), ptr(xt), ptr(t_dev), ptr(pt)
+    d.B, d.L, d.K, d.T = B, L, K, T
+    for i in range(8):
+        d.sched[i] = ptr(sched[i])
+    d.mask_weight[0], d.mask_weight[1] = float(mask_weight[0]), float(mask_weight[1])
+    d.aux_weight, d.adaptive_aux = float(aux_weight), int(bool(adaptive_aux))
+    d.kl, d.nll, d.aux = ptr(scratch[0]), ptr(scratch[1]), ptr(scratch[2])
+    d.x0_recon, d.xt1_recon = ptr(out["x0_recon"]), ptr(out["xt1_recon"])
+    d.Lt_history, d.Lt_count = ptr(Lt_history), ptr(Lt_count)
+    d.loss, d.per_sample, d.probs = ptr(out["loss"]), ptr(out["per_sample"]), None
+    dlogits = torch.empty_like(logits)
+    check(lib().gsdd_d3pm_train_loss_grad(C.byref(d), ptr(dlogits), stream_ptr(stream)))
+    return out, dlogits
+
+
 def advance(t_dev, dt, stream_dev, ds, stream=None):
     B = 0 if t_dev is None else t_dev.numel()
     check(lib().gsdd_advance(ptr(t_dev), B, dt, ptr(stream_dev), ds, stream_ptr(stream)))

@@ -309,6 +309,9 @@ int gsdd_d3pm_train_loss(const gsdd_train_desc* d, void* stream);
 
 /* dlogits = d loss / d logits of the objective above (backward of predict_start -> q_posterior -> KL / NLL / aux KL). */
 int gsdd_d3pm_train_loss_bwd(const gsdd_train_desc* d, float* dlogits, void* stream);
+/* Both of the above in ONE pass over the logits (the training step's path; d->probs must be NULL): every output of
+ * gsdd_d3pm_train_loss, bit-identical, plus dlogits. */
+int gsdd_d3pm_train_loss_grad(const gsdd_train_desc* d, float* dlogits, void* stream);
 
 /* ------------------------------------------------------------------ D3PM training step: backward building blocks
  * (autograd of transformer_utils.py:24-62, 138-159, 258-282, 353-356 and dalle_mask_image_embedding.py:59-79) */

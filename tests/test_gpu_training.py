@@ -67,6 +67,36 @@ def test_loss_gradients_match_autograd_of_oracle(G, golden, tvals):
     print("worst relative gradient error:", worst)
 
 
+@pytest.mark.parametrize("K", [32, 4096])
+def test_fused_loss_and_gradient_pass_equals_the_two_kernels(G, K):
+    """gsdd_d3pm_train_loss_grad (one pass over the logits: loss terms, arg-max tokens, Lt statistics AND dlogits) against
+    gsdd_d3pm_train_loss + gsdd_d3pm_train_loss_bwd: every output bit for bit, incl. t = 0 (the NLL branch) and [MASK] positions."""
+    torch.manual_seed(K)
+    B, L, T = 3, 96, 100
+    d = G.DalleMaskImageEmbedding(num_embed=K, spatial_size=[16, 8], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                 content_spatial_size=[16, 8], diffusion_step=T)
+    dm = G.DiffusionTransformer(transformer=tr, diffusion_step=T, alpha_init_type="alpha1", auxiliary_loss_weight=5e-4,
+                                adaptive_auxiliary_loss=True, guidance_scale=2, content_seq_len=L).cuda()
+    logits = (3.0 * torch.randn(B * L, K)).cuda()
+    x0 = torch.randint(0, K, (B, L)).cuda()
+    xt = x0.clone()
+    xt[torch.rand(B, L, device="cuda") < 0.5] = K
+    xt[0, :5] = torch.randint(0, K, (5,)).cuda()                  # a few unmasked positions that differ from x0
+    t = torch.tensor([0, 37, 99]).cuda()
+    pt = torch.tensor([0.01, 0.02, 0.005]).cuda()
+    kw = dict(K=K, T=T, mask_weight=[1.0, 0.7], aux_weight=5e-4, adaptive_aux=True)
+    h0, c0 = torch.rand(T).cuda(), torch.randint(0, 20, (T,)).float().cuda()
+    ha, ca, hb, cb = h0.clone(), c0.clone(), h0.clone(), c0.clone()
+    fa = G.ops.d3pm_train_loss(logits, x0, xt, t, pt, dm._sched(), ha, ca, want_probs=False, **kw)
+    ga = G.ops.d3pm_train_loss_bwd(logits, x0, xt, t, pt, dm._sched(), **kw)
+    fb, gb = G.ops.d3pm_train_loss_grad(logits, x0, xt, t, pt, dm._sched(), hb, cb, **kw)
+    for k_ in ("loss", "per_sample", "x0_recon", "xt1_recon"):
+        assert torch.equal(fa[k_], fb[k_]), k_
+    assert torch.equal(ga, gb) and torch.equal(ha, hb) and torch.equal(ca, cb)
+    assert bool(torch.isfinite(gb).all()) and float(gb.abs().max()) > 0
+
+
 def test_loss_gradients_full_size_two_layers(G):
     """Gradient parity at the workload's own sequence and class counts (L = 4096 tokens, K = 4096 codes, one clip, TWO of the 19
     layers: the oracle's autograd keeps 16 x 4096^2 scores per layer): every parameter gradient against torch.autograd of the CPU
