@@ -350,8 +350,12 @@ struct TrainArgs {
     float* probs;             // optional [B][K+1][L] = exp(log_model)
 };
 
-template <int J>
-__global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, SchedPtrs sp) {
+// (two waves per SIMD: left to itself the compiler interleaves so many classes of the unrolled loops that it needs 256 VGPRs plus
+// AGPR spill space, i.e. one wave per SIMD with nothing to cover its transcendentals' latency)
+// FULL: K == 256 J, every register slot holds a class: no validity predicates (each `k < K` otherwise becomes an exec-mask region
+// around its class: 245 s_and_saveexec + 291 branches per position in the K = 4096 instantiation).
+template <int J, bool FULL = false>
+__global__ __launch_bounds__(256, 2) void d3pm_train_loss_kernel(TrainArgs d, SchedPtrs sp) {
     const int lane = threadIdx.x & 63;
     const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pos >= (int64_t)d.B * d.L) return;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k = 4 * lane + 256 * j;
-        if (k < K) {
+        if (FULL || k < K) {
             const float4 v = *reinterpret_cast<const float4*>(row + k);
             xr[j][0] = v.x; xr[j][1] = v.y; xr[j][2] = v.z; xr[j][3] = v.w;
         } else {
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
     log_softmax_clamp<J>(xr);                       // log_x0_recon rows k < K; row K is -70
     const int64_t t = d.t_dev[b];
     const StepSched s = load_sched(sp.p, t, d.T);
-    const int64_t xt = d.xt[pos], x0 = d.x0[pos];
+    const int xt = (int)d.xt[pos], x0 = (int)d.x0[pos];       // (32-bit: the per-class compares are half-rate 64-bit ones otherwise)
     const bool masked = (xt == K);
     const float qt_hit = lae(0.f + s.lca, s.lcb), qt_miss = lae(LOG_ZERO + s.lca, s.lcb);
     const float q1_hit = lae(0.f + s.la, s.lb), q1_miss = lae(LOG_ZERO + s.la, s.lb);
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
         for (int e = 0; e < 4; ++e) {
             const int k = 4 * lane + 256 * j + e;
             const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-            if (k < K) {
+            if (FULL || k < K) {
                 if (xr[j][e] > best0) { best0 = xr[j][e]; best0_k = k; }
                 qm[j][e] = xr[j][e] - log_qt;
                 mxm = fmaxf(mxm, qm[j][e]);
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = 4 * lane + 256 * j + e;
-            if (k < K) {
+            if (FULL || k < K) {
                 const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
                 sem += exp_term(qm[j][e] - mxm);                                 // terms of sums: see exp_term
                 set += exp_term(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(256) void d3pm_train_loss_kernel(TrainArgs d, Sched
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = 4 * lane + 256 * j + e;
-            if (k < K) {
+            if (FULL || k < K) {
                 const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
                 const float log_q1 = masked ? s.lc : (k == xt ? q1_hit : q1_miss);
                 const float lm = clamp70(lae((qm[j][e] - Sm) + s.pca, s.pcb) + log_q1 + Sm);
@@ -539,10 +543,10 @@ struct TrainBwdArgs {
 // LOSS = true (gsdd_d3pm_train_loss_grad): the same pass also leaves what d3pm_train_loss_kernel computes -- the per-position KL /
 // NLL / auxiliary-KL sums and the two arg-max tokens, by the same operations in the same order (bit-identical values) -- so the
 // training step reads the (B L, K) logits once instead of twice and evaluates the posteriors once (1.7 ms of a 67 ms step at bs 16).
-template <int J, bool LOSS = false>
-__global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, SchedPtrs sp) {
+template <int J, bool LOSS = false, bool FULL = false>
+__global__ __launch_bounds__(256, 2) void d3pm_train_bwd_kernel(TrainBwdArgs d, SchedPtrs sp) {
     const int lane = threadIdx.x & 63;
-    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t pos = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (pos >= (int64_t)d.B * d.L) return;
     const int b = (int)(pos / d.L);
     const int K = d.K;
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k = 4 * lane + 256 * j;
-        if (k < K) {
+        if (FULL || k < K) {
             const float4 v = *reinterpret_cast<const float4*>(row + k);
             a[j][0] = v.x; a[j][1] = v.y; a[j][2] = v.z; a[j][3] = v.w;
         } else {
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = 4 * lane + 256 * j + e;
-                if (k < K) {
+                if (FULL || k < K) {
                     const float xr = clamp70(a[j][e]);
                     if (xr > best0) { best0 = xr; best0_k = k; }
                 }
@@ -596,10 +600,18 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
     }
     const int64_t t = d.t_dev[b];
     const StepSched s = load_sched(sp.p, t, d.T);
-    const int64_t xt = d.xt[pos], x0 = d.x0[pos];
+    const int xt = (int)d.xt[pos], x0 = (int)d.x0[pos];
     const bool masked = (xt == K);
     const float qt_hit = lae(0.f + s.lca, s.lcb), qt_miss = lae(LOG_ZERO + s.lca, s.lcb);
     const float q1_hit = lae(0.f + s.la, s.lb), q1_miss = lae(LOG_ZERO + s.la, s.lb);
+    // Everything that depends only on the position is wave-uniform (pos comes through readfirstlane, so x_t, x_0, t and the schedule
+    // row are scalar loads).  The two classes that are special -- k = x_t (the "hit" transition constants) and k = x_0 (the one-hot of
+    // the true posterior) -- sit in register quads xj = x_t / 256 and x0j = x_0 / 256: every other quad runs with scalar constants, and
+    // only those (at most two) quads evaluate per-class selects.  With a select per class in every pass the compiler kept 64-entry
+    // vectors of them alive across the passes: 256 VGPRs + AGPR / scratch spills and one wave per SIMD.
+    const int xj = masked ? -1 : (xt >> 8), x0j = x0 >> 8;
+    const float qt_c = masked ? s.lcc : qt_miss, q1_c = masked ? s.lc : q1_miss;       // the constants of a plain class
+    const float E30 = expf(LOG_ZERO);
     // per-sample weights
     const float m0 = (t == 0) ? 1.f : 0.f;
     const float mw = masked ? d.mw_mask : d.mw_other;
@@ -608,72 +620,70 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
     const float g_kl = (1.f - m0) * mw * inv;
     const float g_nll = m0 * (1.f + w * d.aux_weight) * inv;
     const float g_aux = (1.f - m0) * w * d.aux_weight * mw * inv;
-    // normalisers of the model / true posteriors
-    float mxm = LOG_ZERO, mxt = LOG_ZERO;
+    // walks the classes of the row: f(j, e, k, log_qt, log_q1, lx0, w0) with the constants of class k
+    auto for_classes = [&](auto f) {
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j) {
+            if (j == xj || j == x0j) {                                                  // scalar branch
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            if (k < K) {
-                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                mxm = fmaxf(mxm, clamp70(a[j][e]) - log_qt);
-                mxt = fmaxf(mxt, (k == x0 ? 0.f : LOG_ZERO) - log_qt);
-            }
-        }
-    mxm = wave_max(mxm); mxt = wave_max(mxt);
-    float sem = 0.f, set = 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * lane + 256 * j + e;
+                    if (FULL || k < K) {
+                        const bool hit = !masked && k == xt, tru = k == x0;
+                        f(j, e, k, hit ? qt_hit : qt_c, hit ? q1_hit : q1_c, tru ? 0.f : LOG_ZERO, tru ? 1.f : E30);
+                    }
+                }
+            } else {
 #pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            if (k < K) {
-                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                sem += exp_term((clamp70(a[j][e]) - log_qt) - mxm);
-                set += exp_term(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
-            }
-        }
-    sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
-    set = wave_sum(set) + expf(LOG_ZERO - mxt);
-    const float Sm = mxm + logf(sem), St = mxt + logf(set);
-    const float E30 = expf(LOG_ZERO);
-    // pass A: Gqn_c and the gradient reaching S
-    float gq[J][4];
-    float sumGe = 0.f, sumGqn = 0.f;
-    float kl = 0.f, nll = 0.f, aux = 0.f;           // LOSS: the forward kernel's three sums and the arg-max of log_model
-    float bestm = NEG; int bestm_k = 0;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            gq[j][e] = 0.f;
-            if (k < K) {
-                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                const float log_q1 = masked ? s.lc : (k == xt ? q1_hit : q1_miss);
-                const float xr = clamp70(a[j][e]);
-                const float qn = (xr - log_qt) - Sm;
-                const float ee = lae(qn + s.pca, s.pcb);
-                const float pre = ee + log_q1 + Sm;
-                const float lx0 = (k == x0 ? 0.f : LOG_ZERO);
-                const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
-                const float eltr = exp_le0(ltr);
-                const float w0 = (k == x0 ? 1.f : E30);
-                const float G = -(g_kl * eltr + g_nll * w0);
-                const float Ge = (pre >= -70.f && pre <= 0.f) ? G : 0.f;
-                const float Gqn = Ge * exp_le0((qn + s.pca) - ee);
-                gq[j][e] = Gqn;
-                sumGe += Ge; sumGqn += Gqn;
-                if (LOSS) {
-                    const float lm = clamp70(pre);
-                    kl += eltr * (ltr - lm);
-                    nll += w0 * lm;
-                    aux += w0 * (lx0 - xr);
-                    if (lm > bestm) { bestm = lm; bestm_k = k; }
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * lane + 256 * j + e;
+                    if (FULL || k < K) f(j, e, k, qt_c, q1_c, LOG_ZERO, E30);
                 }
             }
         }
+    };
+    // normalisers of the model / true posteriors
+    float mxm = LOG_ZERO, mxt = LOG_ZERO;
+    for_classes([&](int j, int e, int, float log_qt, float, float lx0, float) {
+        mxm = fmaxf(mxm, clamp70(a[j][e]) - log_qt);
+        mxt = fmaxf(mxt, lx0 - log_qt);
+    });
+    mxm = wave_max(mxm); mxt = wave_max(mxt);
+    float sem = 0.f, set = 0.f;
+    for_classes([&](int j, int e, int, float log_qt, float, float lx0, float) {
+        sem += exp_term((clamp70(a[j][e]) - log_qt) - mxm);
+        set += exp_term((lx0 - log_qt) - mxt);
+    });
+    sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
+    set = wave_sum(set) + expf(LOG_ZERO - mxt);
+    const float Sm = mxm + logf(sem), St = mxt + logf(set);
+    // pass A: Gqn_c and the gradient reaching S.  The per-class gradient under construction lives in LDS (one 16-byte slot per lane
+    // and register quad, lane-contiguous: conflict-free b128 accesses), not in a second 64-register array.
+    extern __shared__ __attribute__((aligned(16))) float gq_lds[];
+    float* const gqs = gq_lds + (((threadIdx.x >> 6) * J) * 64 + lane) * 4;            // class (j, e) at gqs[256 j + e]
+    float sumGe = 0.f, sumGqn = 0.f;
+    float kl = 0.f, nll = 0.f, aux = 0.f;           // LOSS: the forward kernel's three sums and the arg-max of log_model
+    float bestm = NEG; int bestm_k = 0;
+    for_classes([&](int j, int e, int k, float log_qt, float log_q1, float lx0, float w0) {
+        const float xr = clamp70(a[j][e]);
+        const float qn = (xr - log_qt) - Sm;
+        const float ee = lae(qn + s.pca, s.pcb);
+        const float pre = ee + log_q1 + Sm;
+        const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
+        const float eltr = exp_le0(ltr);
+        const float G = -(g_kl * eltr + g_nll * w0);
+        const float Ge = (pre >= -70.f && pre <= 0.f) ? G : 0.f;
+        const float Gqn = Ge * exp_le0((qn + s.pca) - ee);
+        gqs[256 * j + e] = Gqn;
+        sumGe += Ge; sumGqn += Gqn;
+        if (LOSS) {
+            const float lm = clamp70(pre);
+            kl += eltr * (ltr - lm);
+            nll += w0 * lm;
+            aux += w0 * (lx0 - xr);
+            if (lm > bestm) { bestm = lm; bestm_k = k; }
+        }
+    });
     sumGe = wave_sum(sumGe); sumGqn = wave_sum(sumGqn);
     if (LOSS) { kl = wave_sum(kl); nll = wave_sum(nll); aux = wave_sum(aux); }
     {   // the [MASK] class: q_K is a constant, it only feeds S
@@ -707,32 +717,26 @@ __global__ __launch_bounds__(256) void d3pm_train_bwd_kernel(TrainBwdArgs d, Sch
     const float GS = sumGe - sumGqn;
     // pass B: through q -> r -> clamp -> log_softmax
     float sumGa = 0.f;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            if (k < K) {
-                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                const float r = clamp70(a[j][e]);
-                const float pi = exp_le0((r - log_qt) - Sm);
-                float Gr = gq[j][e] + GS * pi;
-                Gr -= g_aux * (k == x0 ? 1.f : E30);
-                const float Ga = (a[j][e] >= -70.f && a[j][e] <= 0.f) ? Gr : 0.f;
-                gq[j][e] = Ga;
-                sumGa += Ga;
-            }
-        }
+    for_classes([&](int j, int e, int, float log_qt, float, float, float w0) {
+        const float r = clamp70(a[j][e]);
+        const float pi = exp_le0((r - log_qt) - Sm);
+        float Gr = gqs[256 * j + e] + GS * pi;
+        Gr -= g_aux * w0;
+        const float Ga = (a[j][e] >= -70.f && a[j][e] <= 0.f) ? Gr : 0.f;
+        gqs[256 * j + e] = Ga;
+        sumGa += Ga;
+    });
     sumGa = wave_sum(sumGa);
     float* drow = d.dlogits + pos * (int64_t)K;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int k = 4 * lane + 256 * j;
-        if (k < K) {
+        if (FULL || k < K) {
             float4 o;
+            const float4 gv = *reinterpret_cast<const float4*>(gqs + 256 * j);
             // softmax probabilities of the gradient (relative error of exp_term: |a| 1.7e-7, at most 1.2e-5 and only where p < e^-69)
-            o.x = gq[j][0] - exp_term(a[j][0]) * sumGa; o.y = gq[j][1] - exp_term(a[j][1]) * sumGa;
-            o.z = gq[j][2] - exp_term(a[j][2]) * sumGa; o.w = gq[j][3] - exp_term(a[j][3]) * sumGa;
+            o.x = gv.x - exp_term(a[j][0]) * sumGa; o.y = gv.y - exp_term(a[j][1]) * sumGa;
+            o.z = gv.z - exp_term(a[j][2]) * sumGa; o.w = gv.w - exp_term(a[j][3]) * sumGa;
             *reinterpret_cast<float4*>(drow + k) = o;
         }
     }
@@ -835,7 +839,8 @@ extern "C" int gsdd_d3pm_train_loss(const gsdd_train_desc* d, void* stream) {
     const dim3 grid((unsigned)((npos + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int J = (d->K + 255) / 256;
-    if (J <= 1) hipLaunchKernelGGL(d3pm_train_loss_kernel<1>, grid, block, 0, st, a, sp);
+    if (d->K == 4096) hipLaunchKernelGGL((d3pm_train_loss_kernel<16, true>), grid, block, 0, st, a, sp);
+    else if (J <= 1) hipLaunchKernelGGL(d3pm_train_loss_kernel<1>, grid, block, 0, st, a, sp);
     else if (J <= 2) hipLaunchKernelGGL(d3pm_train_loss_kernel<2>, grid, block, 0, st, a, sp);
     else if (J <= 4) hipLaunchKernelGGL(d3pm_train_loss_kernel<4>, grid, block, 0, st, a, sp);
     else if (J <= 8) hipLaunchKernelGGL(d3pm_train_loss_kernel<8>, grid, block, 0, st, a, sp);
@@ -895,12 +900,21 @@ static int train_bwd_launch(const gsdd_train_desc* d, float* dlogits, bool with_
     const dim3 grid((unsigned)((npos + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int J = (d->K + 255) / 256;
-#define GSDD_BWD_LAUNCH(JJ)                                                                                   \
-    do {                                                                                                      \
-        if (with_loss) hipLaunchKernelGGL((d3pm_train_bwd_kernel<JJ, true>), grid, block, 0, st, a, sp);      \
-        else hipLaunchKernelGGL((d3pm_train_bwd_kernel<JJ, false>), grid, block, 0, st, a, sp);               \
+    // dynamic LDS: one float4 per (wave, register quad, lane) = 4 KB * J per workgroup (64 KB at K = 4096: two workgroups per CU)
+#define GSDD_BWD_LAUNCH(JJ)                                                                                                   \
+    do {                                                                                                                      \
+        if (with_loss) hipLaunchKernelGGL((d3pm_train_bwd_kernel<JJ, true>), grid, block, (size_t)4096 * JJ, st, a, sp);      \
+        else hipLaunchKernelGGL((d3pm_train_bwd_kernel<JJ, false>), grid, block, (size_t)4096 * JJ, st, a, sp);               \
     } while (0)
-    if (J <= 1) GSDD_BWD_LAUNCH(1);
+    static unsigned long long attr_done = 0ull;     // J = 32 (K up to 8192) needs 128 KB of dynamic LDS: above the 64 KB default
+    if (first_on_device(attr_done)) {
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_train_bwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_train_bwd_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+    }
+    if (d->K == 4096) {                            // the workload's class count: every register slot holds a class
+        if (with_loss) hipLaunchKernelGGL((d3pm_train_bwd_kernel<16, true, true>), grid, block, (size_t)4096 * 16, st, a, sp);
+        else hipLaunchKernelGGL((d3pm_train_bwd_kernel<16, false, true>), grid, block, (size_t)4096 * 16, st, a, sp);
+    } else if (J <= 1) GSDD_BWD_LAUNCH(1);
     else if (J <= 2) GSDD_BWD_LAUNCH(2);
     else if (J <= 4) GSDD_BWD_LAUNCH(4);
     else if (J <= 8) GSDD_BWD_LAUNCH(8);
