@@ -609,8 +609,10 @@ __global__ __launch_bounds__(256, 2) void d3pm_train_bwd_kernel(TrainBwdArgs d, 
     // the true posterior) -- sit in register quads xj = x_t / 256 and x0j = x_0 / 256: every other quad runs with scalar constants, and
     // only those (at most two) quads evaluate per-class selects.  With a select per class in every pass the compiler kept 64-entry
     // vectors of them alive across the passes: 256 VGPRs + AGPR / scratch spills and one wave per SIMD.
+    // (named scalars, not the struct: a struct captured by reference in the class-walking lambdas is demoted to scratch memory)
+    const float s_pca = s.pca, s_pcb = s.pcb, s_p1mcc = s.p1mcc, s_pcc = s.pcc, s_lcc = s.lcc, s_lc = s.lc;
     const int xj = masked ? -1 : (xt >> 8), x0j = x0 >> 8;
-    const float qt_c = masked ? s.lcc : qt_miss, q1_c = masked ? s.lc : q1_miss;       // the constants of a plain class
+    const float qt_c = masked ? s_lcc : qt_miss, q1_c = masked ? s_lc : q1_miss;       // the constants of a plain class
     const float E30 = expf(LOG_ZERO);
     // per-sample weights
     const float m0 = (t == 0) ? 1.f : 0.f;
@@ -667,13 +669,13 @@ __global__ __launch_bounds__(256, 2) void d3pm_train_bwd_kernel(TrainBwdArgs d, 
     for_classes([&](int j, int e, int k, float log_qt, float log_q1, float lx0, float w0) {
         const float xr = clamp70(a[j][e]);
         const float qn = (xr - log_qt) - Sm;
-        const float ee = lae(qn + s.pca, s.pcb);
+        const float ee = lae(qn + s_pca, s_pcb);
         const float pre = ee + log_q1 + Sm;
-        const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
+        const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s_pca, s_pcb) + log_q1 + St);
         const float eltr = exp_le0(ltr);
         const float G = -(g_kl * eltr + g_nll * w0);
         const float Ge = (pre >= -70.f && pre <= 0.f) ? G : 0.f;
-        const float Gqn = Ge * exp_le0((qn + s.pca) - ee);
+        const float Gqn = Ge * exp_le0((qn + s_pca) - ee);
         gqs[256 * j + e] = Gqn;
         sumGe += Ge; sumGqn += Gqn;
         if (LOSS) {
@@ -689,14 +691,14 @@ __global__ __launch_bounds__(256, 2) void d3pm_train_bwd_kernel(TrainBwdArgs d, 
     {   // the [MASK] class: q_K is a constant, it only feeds S
         const float log_q1K = masked ? 0.f : LOG_ZERO;
         const float qnK = LOG_ZERO - Sm;
-        const float eK = lae(qnK + s.p1mcc, s.pcc);
+        const float eK = lae(qnK + s_p1mcc, s_pcc);
         const float preK = eK + log_q1K + Sm;
-        const float ltK = clamp70(lae((LOG_ZERO - St) + s.p1mcc, s.pcc) + log_q1K + St);
+        const float ltK = clamp70(lae((LOG_ZERO - St) + s_p1mcc, s_pcc) + log_q1K + St);
         const float eltK = expf(ltK);
         const float GK = -(g_kl * eltK + g_nll * (x0 == K ? 1.f : E30));
         const float GeK = (preK >= -70.f && preK <= 0.f) ? GK : 0.f;
         sumGe += GeK;
-        sumGqn += GeK * expf((qnK + s.p1mcc) - eK);
+        sumGqn += GeK * expf((qnK + s_p1mcc) - eK);
         if (LOSS) {
             const float lmK = clamp70(preK);
             kl += eltK * (ltK - lmK);
