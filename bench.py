@@ -24,9 +24,10 @@ import gsdd_amd  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA peak
 # GSDD_ATTN_P -> (kernel template argument, what the softmax probabilities are carried as into the P.V product)
-P_MODES = {"a8": (8, "f16 hi (11 bits), + f16 lo (22 bits) in every (16-query, 32-key) tile that holds a probability above 2^-8 of "
-                     "its row's running sum (measured logits error vs the fp32 oracle at full size: 8e-6 init weights, 1.5e-5 "
-                     "trained-like; all-tiles hi+lo = GSDD_ATTN_P=22: 1.3e-6 / 8.5e-6)"),
+P_MODES = {"a8": (8, "f16 hi (11 bits), + f16 lo (22 bits) in every (16-query, 32-key) tile that can hold a probability above 2^-8 of "
+                     "its row's sum -- cleared by a ||q|| ||k|| bound where that proves it cannot, measured otherwise (logits error vs "
+                     "the fp32 oracle at full size: 8e-6 init weights, 1.3e-5 trained-like; all-tiles hi+lo = GSDD_ATTN_P=22: 1.3e-6 / "
+                     "8.5e-6)"),
            "a12": (12, "f16 hi, + lo where a probability exceeds 2^-12 of the row's running sum"),
            "22": (1, "f16 hi + lo (22 bits) everywhere"), "11": (0, "f16 hi only (11 bits)")}
 HBM_PEAK_GBS = 8000.0

@@ -576,7 +576,11 @@ extern "C" int gsdd_wgrad(const float* dY, int ldy, const float* X, int ldx, int
                           void* stream) {
     GSDD_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0, "bad args");
     GSDD_CHECK_ARG(N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0, "N, K and pitches must be multiples of 4");
-    const int slabs = 8;
+    // 8 slabs of 128 rows per workgroup amortise the atomic pass, but a 64 x 64 weight over 65536 rows is then 64 workgroups on 256
+    // CUs: fewer slabs until the grid reaches ~2 workgroups per CU
+    int slabs = 8;
+    const int64_t tiles = (int64_t)((N + 63) / 64) * ((K + 63) / 64);
+    while (slabs > 1 && ((M + (int64_t)WG_ROWS * slabs - 1) / ((int64_t)WG_ROWS * slabs)) * tiles < 512) slabs >>= 1;
     const dim3 grid((unsigned)((M + (int64_t)WG_ROWS * slabs - 1) / ((int64_t)WG_ROWS * slabs)), (N + 63) / 64, (K + 63) / 64);
     hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, dW, slabs, db);
     GSDD_CHECK_LAUNCH();
