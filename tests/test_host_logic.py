@@ -385,3 +385,45 @@ def test_clip_folder_datamodule_shards_whole_rounds(tmp_path, monkeypatch):
         for r, (b, read) in enumerate(per_rank):
             assert b == [single[i * world + r] for i in range(rounds)]
             assert len(read) == 2 * rounds            # only its own clips were read and preprocessed
+
+
+def test_clip_text_provider_runs_a_supplied_local_tower(tmp_path):
+    """`CLIPTextEmbedding(weights=<local directory>)`: the reference's recipe (clip_text_embedding.py:56-64: tokens truncated to
+    start + 20 + end, ids zero-padded to 77, the projected feature at the end-of-text token) on a tower loaded from disk -- here a
+    small randomly initialised one of the CLIP text architecture with a byte-level vocabulary, since neither ViT-B/32 nor its BPE
+    table exist offline (parity with `clip.encode_text` itself is therefore unpinned).  Without `weights`: the hash stand-in."""
+    transformers = pytest.importorskip("transformers")
+    import src  # noqa: F401
+    from src.models.text_models.clip_text_embedding import CLIPTextEmbedding
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    chars = [chr(c) for c in cs]
+    vocab = {c: i for i, c in enumerate(chars)}
+    vocab.update({c + "</w>": 256 + i for i, c in enumerate(chars)})
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = 512, 513
+    transformers.CLIPTokenizer(vocab=vocab, merges=[]).save_pretrained(tmp_path)
+    cfg = transformers.CLIPTextConfig(vocab_size=514, hidden_size=32, intermediate_size=64, projection_dim=16, num_hidden_layers=2,
+                                      num_attention_heads=2, max_position_embeddings=77, bos_token_id=512, eos_token_id=513, pad_token_id=0)
+    torch.manual_seed(0)
+    tower = transformers.CLIPTextModelWithProjection(cfg)
+    tower.save_pretrained(tmp_path)
+    p = CLIPTextEmbedding(clip_dim=16, weights=str(tmp_path))
+    assert not any(q.requires_grad for q in p.clip_model.parameters()) and not p.train().clip_model.training
+    texts = ["a dog runs", "x" * 40, ""]
+    ids = p.tokenize(texts)
+    assert tuple(ids.shape) == (3, 77) and ids[0, 0] == 512 and int((ids[1] != 0).sum()) == 22 and ids[1, 21] == 513
+    assert ids[2, :3].tolist() == [512, 513, 0]
+    out = p(texts)
+    with torch.no_grad():
+        want = tower.eval()(input_ids=ids).text_embeds
+    assert tuple(out.shape) == (3, 16) and out.dtype == torch.float32
+    torch.testing.assert_close(out, want, atol=1e-6, rtol=1e-6)
+    with pytest.raises(FileNotFoundError):
+        CLIPTextEmbedding(clip_dim=16, weights=str(tmp_path / "missing"))
+    with pytest.raises(ValueError):
+        CLIPTextEmbedding(clip_dim=512, weights=str(tmp_path))
+    h = CLIPTextEmbedding(clip_dim=512)(["a", "b", "a"])
+    assert tuple(h.shape) == (3, 512) and torch.equal(h[0], h[2]) and not torch.equal(h[0], h[1])
