@@ -357,7 +357,7 @@ struct TrainArgs {
 template <int J, bool FULL = false>
 __global__ __launch_bounds__(256, 2) void d3pm_train_loss_kernel(TrainArgs d, SchedPtrs sp) {
     const int lane = threadIdx.x & 63;
-    const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t pos = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (pos >= (int64_t)d.B * d.L) return;
     const int b = (int)(pos / d.L), l = (int)(pos % d.L);
     const int K = d.K;
@@ -381,73 +381,70 @@ __global__ __launch_bounds__(256, 2) void d3pm_train_loss_kernel(TrainArgs d, Sc
     const bool masked = (xt == K);
     const float qt_hit = lae(0.f + s.lca, s.lcb), qt_miss = lae(LOG_ZERO + s.lca, s.lcb);
     const float q1_hit = lae(0.f + s.la, s.lb), q1_miss = lae(LOG_ZERO + s.la, s.lb);
-    // pass 1: the two normalisers S_m (model) and S_t (true)
-    float qm[J][4];
-    float mxm = LOG_ZERO, mxt = LOG_ZERO;            // include the [MASK] row (= LOG_ZERO) in both maxima
-    float best0 = NEG; int best0_k = 0;              // arg-max of log_x0_recon (row K = -70 competes)
+    // As in d3pm_train_bwd_kernel: the position is wave-uniform, the two special classes (k = x_t, k = x_0) sit in register quads
+    // xj / x0j, every other quad runs on scalar constants behind a scalar branch; no second 64-register array (q = x - log_qt is
+    // recomputed: one subtraction).
+    const int xj = masked ? -1 : (xt >> 8), x0j = x0 >> 8;
+    const float qt_c = masked ? s.lcc : qt_miss, q1_c = masked ? s.lc : q1_miss;
+    const float E30 = expf(LOG_ZERO);               // exp(log-onehot "zero") as the reference computes it
+    const float s_pca = s.pca, s_pcb = s.pcb, s_p1mcc = s.p1mcc, s_pcc = s.pcc;
+    auto for_classes = [&](auto f) {
 #pragma unroll
-    for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j) {
+            if (j == xj || j == x0j) {                                                  // scalar branch
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-            if (FULL || k < K) {
-                if (xr[j][e] > best0) { best0 = xr[j][e]; best0_k = k; }
-                qm[j][e] = xr[j][e] - log_qt;
-                mxm = fmaxf(mxm, qm[j][e]);
-                mxt = fmaxf(mxt, (k == x0 ? 0.f : LOG_ZERO) - log_qt);
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * lane + 256 * j + e;
+                    if (FULL || k < K) {
+                        const bool hit = !masked && k == xt, tru = k == x0;
+                        f(j, e, k, hit ? qt_hit : qt_c, hit ? q1_hit : q1_c, tru ? 0.f : LOG_ZERO, tru ? 1.f : E30);
+                    }
+                }
             } else {
-                qm[j][e] = NEG;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * lane + 256 * j + e;
+                    if (FULL || k < K) f(j, e, k, qt_c, q1_c, LOG_ZERO, E30);
+                }
             }
         }
-    {   // row K of log_x0_recon is -70: first-max rule across the whole wave handled by wave_argmax (lowest index wins ties)
-        if (lane == 0 && -70.f > best0) { best0 = -70.f; best0_k = K; }
-    }
+    };
+    // pass 1: the two normalisers S_m (model) and S_t (true); arg-max of log_x0_recon (row K = -70 competes)
+    float mxm = LOG_ZERO, mxt = LOG_ZERO;            // include the [MASK] row (= LOG_ZERO) in both maxima
+    float best0 = NEG; int best0_k = 0;
+    for_classes([&](int j, int e, int k, float log_qt, float, float lx0, float) {
+        if (xr[j][e] > best0) { best0 = xr[j][e]; best0_k = k; }
+        mxm = fmaxf(mxm, xr[j][e] - log_qt);
+        mxt = fmaxf(mxt, lx0 - log_qt);
+    });
+    if (lane == 0 && -70.f > best0) { best0 = -70.f; best0_k = K; }     // first-max rule across the wave: wave_argmax
     const int x0rec = wave_argmax(best0, best0_k);
     mxm = wave_max(mxm); mxt = wave_max(mxt);
     float sem = 0.f, set = 0.f;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            if (FULL || k < K) {
-                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                sem += exp_term(qm[j][e] - mxm);                                 // terms of sums: see exp_term
-                set += exp_term(((k == x0 ? 0.f : LOG_ZERO) - log_qt) - mxt);
-            }
-        }
+    for_classes([&](int j, int e, int, float log_qt, float, float lx0, float) {
+        sem += exp_term((xr[j][e] - log_qt) - mxm);                                      // terms of sums: see exp_term
+        set += exp_term((lx0 - log_qt) - mxt);
+    });
     sem = wave_sum(sem) + expf(LOG_ZERO - mxm);
     set = wave_sum(set) + expf(LOG_ZERO - mxt);
     const float Sm = mxm + logf(sem), St = mxt + logf(set);
     // pass 2: posteriors, KL / NLL / aux partial sums, arg-max of log_model
     float kl = 0.f, nll = 0.f, aux = 0.f;
     float bestm = NEG; int bestm_k = 0;
-    const float E30 = expf(LOG_ZERO);               // exp(log-onehot "zero") as the reference computes it
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * j + e;
-            if (FULL || k < K) {
-                const float log_qt = masked ? s.lcc : (k == xt ? qt_hit : qt_miss);
-                const float log_q1 = masked ? s.lc : (k == xt ? q1_hit : q1_miss);
-                const float lm = clamp70(lae((qm[j][e] - Sm) + s.pca, s.pcb) + log_q1 + Sm);
-                const float lx0 = (k == x0 ? 0.f : LOG_ZERO);
-                const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s.pca, s.pcb) + log_q1 + St);
-                kl += exp_le0(ltr) * (ltr - lm);
-                const float w0 = (k == x0 ? 1.f : E30);
-                nll += w0 * lm;
-                aux += w0 * (lx0 - xr[j][e]);
-                if (lm > bestm) { bestm = lm; bestm_k = k; }
-                if (d.probs != nullptr) d.probs[((int64_t)b * (K + 1) + k) * d.L + l] = exp_le0(lm);
-            }
-        }
+    for_classes([&](int j, int e, int k, float log_qt, float log_q1, float lx0, float w0) {
+        const float lm = clamp70(lae(((xr[j][e] - log_qt) - Sm) + s_pca, s_pcb) + log_q1 + Sm);
+        const float ltr = clamp70(lae(((lx0 - log_qt) - St) + s_pca, s_pcb) + log_q1 + St);
+        kl += exp_le0(ltr) * (ltr - lm);
+        nll += w0 * lm;
+        aux += w0 * (lx0 - xr[j][e]);
+        if (lm > bestm) { bestm = lm; bestm_k = k; }
+        if (d.probs != nullptr) d.probs[((int64_t)b * (K + 1) + k) * d.L + l] = exp_le0(lm);
+    });
     kl = wave_sum(kl); nll = wave_sum(nll); aux = wave_sum(aux);
     {   // the [MASK] class row
         const float log_q1K = masked ? 0.f : LOG_ZERO;
-        const float lmK = clamp70(lae((LOG_ZERO - Sm) + s.p1mcc, s.pcc) + log_q1K + Sm);
-        const float ltK = clamp70(lae((LOG_ZERO - St) + s.p1mcc, s.pcc) + log_q1K + St);
+        const float lmK = clamp70(lae((LOG_ZERO - Sm) + s_p1mcc, s_pcc) + log_q1K + Sm);
+        const float ltK = clamp70(lae((LOG_ZERO - St) + s_p1mcc, s_pcc) + log_q1K + St);
         kl += expf(ltK) * (ltK - lmK);
         nll += (x0 == K ? 1.f : E30) * lmK;
         if (lane == 0) {

@@ -685,7 +685,8 @@ class DiscreteDiffusion(nn.Module):
         with torch.no_grad():
             text_emb = self._text(batch["text"], dev)
         diffusion_out = self.diffusion_model({"condition_embed_token": text_emb, "content_token": quant_flat},
-                                             return_loss=True)
+                                             return_loss=True, return_logits=False)   # (`logits` = exp(log_model_prob), a (B, K+1, L)
+        # tensor the reference computes here and never reads (discrete_diffusion.py:38-41, :66-81): not asked for, so the loss and its gradient take the one-pass kernel)
         with torch.no_grad():
             # arg-max over K+1 classes can only return [MASK] when every code row sits at the -70 clamp; the reference would
             # then fail inside F.embedding, we decode code K-1 instead

@@ -79,6 +79,23 @@ def test_full_reverse_loop_matches_reference(golden):
     assert np.array_equal(tok.numpy(), a["loop_tokens"])
 
 
+def test_long_sequence_fixture_first_steps_match_reference(golden):
+    """`d3pm_L2048`: the reference's own 100-step loop at L = 2048 (where the device's attention kernel switches to its adaptive P
+    arithmetic).  The oracle reproduces the teacher-forced step's logits and sample and the first three steps of the loop trace (the
+    whole loop is 3 minutes of CPU; the device test runs all 100 steps)."""
+    sd, a, cfg = golden("d3pm_L2048")
+    xt, cond, t = torch.from_numpy(a["step_xt"]), torch.from_numpy(a["step_cond"]), torch.from_numpy(a["step_t"])
+    with torch.no_grad():
+        logits = d3pm.denoiser(xt, cond, t, sd)
+        tok, _ = d3pm.p_sample_step(xt, cond, torch.zeros_like(cond), t, sd, cfg["guidance"], cfg["noise_seed"], int(a["step_stream"]))
+        trace = []
+        d3pm.sample(cfg["B"], cfg["L"], cond, torch.zeros_like(cond), sd, cfg["guidance"], cfg["noise_seed"], trace=trace, steps=3)
+    np.testing.assert_allclose(logits.numpy(), a["step_logits"], atol=2e-5, rtol=1e-5)
+    assert np.array_equal(tok.numpy(), a["step_sample"])
+    assert np.array_equal(np.stack([x.numpy() for x in trace]), a["loop_trace"][:3])
+    assert int((a["loop_tokens"] == cfg["K"]).sum()) == 0 and a["loop_trace"].shape == (cfg["T"], cfg["B"], cfg["L"])
+
+
 def test_train_loss_matches_reference(golden):
     sd, a, cfg = golden("d3pm_L64")
     cond = torch.from_numpy(a["step_cond"])
