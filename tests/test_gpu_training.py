@@ -232,6 +232,55 @@ def test_two_rank_data_parallel_step_equals_global_batch(G, golden):
         assert torch.allclose(d1[big], d2[big], atol=5e-6, rtol=5e-2), k
 
 
+def _rccl_one_rank_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", GSDD_REDUCER_FORCE="1")
+    import torch.distributed as dist
+    import gsdd_amd
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    from tests.conftest import load_golden
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl")                  # RCCL, on the real device: a group of one
+    sd, a, cfg = load_golden("d3pm_L64")
+    x0, cond = torch.from_numpy(a["train_x0"]).cuda(), torch.from_numpy(a["step_cond"]).cuda()
+    t, pt = torch.tensor([5, 77]).cuda(), (torch.ones(2) / cfg["T"]).cuda()
+    grads = {}
+    for reduce in (False, True):
+        dm = build(gsdd_amd, sd, cfg)
+        dm.set_noise(cfg["noise_seed"], stream=int(a["train_stream"]))
+        tr = D3PMTrainer(dm)
+        _, g = tr.loss_and_grads(x0, cond, t=t, pt=pt, reduce=reduce)
+        torch.cuda.synchronize()
+        grads[reduce] = {k: v.detach().cpu().clone() for k, v in g.items()}
+        stats = tr.reducer.stats()
+    probe = torch.arange(8, dtype=torch.float32, device="cuda")
+    dist.all_reduce(probe)
+    q.put({"same": all(torch.equal(grads[False][k], grads[True][k]) for k in grads[False]), "stats": stats,
+           "probe": probe.cpu().tolist(), "backend": dist.get_backend()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_initialises_and_carries_the_bucketed_exchange_on_one_gpu(G):
+    """No multi-GPU box is to be had for these tests, so this is what can be shown on hardware: RCCL (backend "nccl") initialises
+    on the MI355X, and the data-parallel gradient exchange -- buckets all-reduced asynchronously on RCCL's stream while the backward
+    is still being enqueued, the compute stream waiting for them at the end -- runs through it with a group of one and leaves the
+    gradients bit-identical to the run without it.  (Two ranks on one device are not possible with RCCL; the 2-rank tests use gloo.)"""
+    import os
+    import torch.multiprocessing as mp
+    from tests.conftest import parity_report
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(29700 + (os.getpid() % 200), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    parity_report("rccl_one_rank_rehearsal", {"backend": got["backend"], "gradients_identical": got["same"], **got["stats"]})
+    assert got["backend"] == "nccl" and got["same"] and got["probe"] == [float(i) for i in range(8)]
+    assert got["stats"].get("allreduce_buckets", 0) >= 2 and got["stats"]["allreduce_mib"] > 0
+
+
 # ----------------------------------------------------------------------------- attention backward kernels vs fp64 autograd
 @pytest.mark.parametrize("mode", ["fused", "split", "valu"])
 @pytest.mark.parametrize("B,L,scale", [(2, 64, 1.0), (1, 320, 1.5), (1, 1024, 1.0), (2, 96, 3.0), (2, 544, 1.0)])
