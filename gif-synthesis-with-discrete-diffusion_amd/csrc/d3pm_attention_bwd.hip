@@ -465,10 +465,17 @@ struct FusedStage {
     uint4 qv[FQC / 32][4][16];
     uint4 gv[FQC / 32][4][16];
 };
+// NW waves per workgroup = NW * 64 keys.  NW = 8 (GSDD_ATTN_BWD_NW=8) lets the query-side chunk staged in LDS serve 512 keys instead
+// of 256: the staging traffic per key and the number of partial dQ copies (one per workgroup and query) halve -- 307 -> 154 MB written
+// and 286 -> 143 MB re-read per layer at bs 16 -- at the same 8 waves per CU (one workgroup of 107 KB of LDS instead of two of 73 KB).
+// Measured (round 3, bs 16, L = 4096): the training step is 2 ms SLOWER with it (65.6-66.2 vs 63.6-64.4 ms; the pair fused + reduce
+// 2.100 vs 2.088 ms in the microbenchmark): one barrier now releases eight lockstep waves instead of four, and what the bytes save is
+// not where the kernel's time is (vector issue 63 %, not memory).  NW = 4 stays the default; the traffic is not the lever here.
+template <int NW>
 struct FusedSmem {
     FusedStage st[2];              // by chunk parity
-    uint2 t[4][2][2][32][4];       // [wave][hi/lo][query tile][key row of the pair][8-byte chunk, XOR-swizzled by (row >> 2) & 3]
-    float dq[2][4][4][FSLAB];      // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
+    uint2 t[NW][2][2][32][4];      // [wave][hi/lo][query tile][key row of the pair][8-byte chunk, XOR-swizzled by (row >> 2) & 3]
+    float dq[2][NW][4][FSLAB];     // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
 };
 
 // ds_read_b64_tr_b16 through the compiler's builtin: it then places the s_waitcnt itself and orders the read after the wave's own
@@ -487,21 +494,22 @@ __device__ __forceinline__ float bw_piece_sum(float x) {
     return (x + a) + b;
 }
 
-template <int DBG>   // 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing experiments only)
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __restrict__ k, const float* __restrict__ v, BwdImages im,
-                                                                int B, int L, int H, float* __restrict__ dqkv,
-                                                                float* __restrict__ dq_part) {
+template <int DBG, int NW = 4>   // DBG 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing only)
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float* __restrict__ k, const float* __restrict__ v, BwdImages im,
+                                                                    int B, int L, int H, float* __restrict__ dqkv,
+                                                                    float* __restrict__ dq_part) {
     extern __shared__ __attribute__((aligned(16))) char fused_raw[];
-    FusedSmem& sm = *reinterpret_cast<FusedSmem*>(fused_raw);
+    FusedSmem<NW>& sm = *reinterpret_cast<FusedSmem<NW>*>(fused_raw);
+    constexpr int NT = 64 * NW, KB = 64 * NW;                         // threads, keys per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nkb = (L + 255) / 256;
+    const int nkb = (L + KB - 1) / KB;
     const unsigned wg = bw_xcd_remap(blockIdx.x, gridDim.x);
     const int kblk = wg % nkb;
     const int h = (wg / nkb) % H, b = wg / (nkb * H);
     const int64_t M = (int64_t)B * L;
     const int64_t hrow0 = (int64_t)h * M + (int64_t)b * L;
     const int li = lane & 15, lg = lane >> 4;
-    const int k0 = kblk * 256 + wave * 64;
+    const int k0 = kblk * KB + wave * 64;
 
     uint4 kfrag[4], vfrag[4];
 #pragma unroll
@@ -533,27 +541,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const float* __r
         const uint4* qvs = im.qv + ((hrow0 + (int64_t)ch * FQC) >> 5) * 64;
         const uint4* gvs = im.gv + ((hrow0 + (int64_t)ch * FQC) >> 5) * 64;
         const int l3 = rows * 3 - 1, l2 = rows * 2 - 1;               // unconditional, clamped loads (see the dQ kernel)
-        rq0 = qs[min(tid, l3)]; rq1 = qs[min(tid + 256, l3)];
-        rg0 = gs[min(tid, l3)]; rg1 = gs[min(tid + 256, l3)];
+        rq0 = qs[min(tid, l3)]; rg0 = gs[min(tid, l3)];
+        if (NT < FQC * 3) { rq1 = qs[min(tid + NT, l3)]; rg1 = gs[min(tid + NT, l3)]; }
         rqv = qvs[min(tid, l2)]; rgv = gvs[min(tid, l2)];
     };
     auto store_chunk = [&](int par) {
         FusedStage& st = sm.st[par];
         uint4* qd = &st.q[0][0];
         uint4* gd = &st.g[0][0];
-        qd[tid] = rq0; gd[tid] = rg0;
-        if (tid < FQC * 3 - 256) { qd[tid + 256] = rq1; gd[tid + 256] = rg1; }
-        (&st.qv[0][0][0])[tid] = rqv;
-        (&st.gv[0][0][0])[tid] = rgv;
+        if (tid < FQC * 3) { qd[tid] = rq0; gd[tid] = rg0; }                    // 384 fragments each
+        if (NT < FQC * 3 && tid < FQC * 3 - NT) { qd[tid + NT] = rq1; gd[tid + NT] = rg1; }
+        if (tid < FQC * 2) {                                                    // 256 fragments each
+            (&st.qv[0][0][0])[tid] = rqv;
+            (&st.gv[0][0][0])[tid] = rgv;
+        }
     };
-    // partial dQ of chunk `ch` (this workgroup's 256 keys = the four waves' slabs) -> dq_part[kblk][h][row][4]; thread = (query, column pair)
+    // partial dQ of chunk `ch` (this workgroup's keys = its waves' slabs) -> dq_part[kblk][h][row][4]; thread = (query, column pair)
     auto flush_dq = [&](int ch) {
         const int q = tid >> 1, c0 = 2 * (tid & 1);
         const int qi = ch * FQC + q;
-        if (qi < L) {
+        if (tid < 2 * FQC && qi < L) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 s0 += sm.dq[ch & 1][w][c0][q];
                 s1 += sm.dq[ch & 1][w][c0 + 1][q];
             }
@@ -728,24 +738,29 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
     if (!split_kernels) {
         float* dq_part = reinterpret_cast<float*>(reinterpret_cast<uint4*>(workspace) + rows * 16);
-        static bool fattr_done = false;
-        if (!fattr_done) {
-            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem)));
-            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem)));
-            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem)));
-            fattr_done = true;
+        static unsigned long long fattr_done = 0ull;      // one bit per device: the attribute is per device
+        if (first_on_device(fattr_done)) {
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem<4>)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem<4>)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem<4>)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem<8>)));
         }
         const char* dbg = getenv("GSDD_FUSED_DBG");
         const int dbgv = dbg ? atoi(dbg) : 0;
-        if (dbgv == 1) hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, grid, dim3(256), sizeof(FusedSmem), st, k, v, im, B, L, H, dqkv, dq_part);
-        else if (dbgv == 2) hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, grid, dim3(256), sizeof(FusedSmem), st, k, v, im, B, L, H, dqkv, dq_part);
-        else hipLaunchKernelGGL(attn_bwd_fused_kernel<0>, grid, dim3(256), sizeof(FusedSmem), st, k, v, im, B, L, H, dqkv, dq_part);
+        const char* nwe = getenv("GSDD_ATTN_BWD_NW");                 // A/B switch (read per call): waves per workgroup, 4 (default) or 8
+        const int nw = (dbgv == 0 && nwe != nullptr && atoi(nwe) == 8) ? 8 : 4;
+        const int kb = 64 * nw, nkb = (L + kb - 1) / kb;
+        const dim3 fgrid((unsigned)(B * H * nkb));
+        if (dbgv == 1) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, 4>), fgrid, dim3(256), sizeof(FusedSmem<4>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (dbgv == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 4>), fgrid, dim3(256), sizeof(FusedSmem<4>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (nw == 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4>), fgrid, dim3(256), sizeof(FusedSmem<4>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 8>), fgrid, dim3(512), sizeof(FusedSmem<8>), st, k, v, im, B, L, H, dqkv, dq_part);
         GSDD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, dq_part, (L + 255) / 256, H,
-                           M, dqkv);
+        hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, dq_part, nkb, H, M, dqkv);
         GSDD_CHECK_LAUNCH();
         *done = 1;
         return GSDD_OK;
