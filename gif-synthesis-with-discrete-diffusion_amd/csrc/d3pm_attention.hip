@@ -289,7 +289,9 @@ __device__ __forceinline__ f16x8 as_h8(uint4 u) {
 }
 // Split 8 probabilities into packed f16 hi / lo fragments (one MFMA A operand each):
 //   hi = f16(p) round-to-nearest (>= 65520 -> inf, which the overflow screen looks for; v_cvt_pkrtz would saturate)
-//   lo = f16(p - hi), the subtraction done by v_fma_mix_f32 reading the f16 half directly (exact in f32)
+//   lo = f16(p - hi), the subtraction done by v_fma_mix_f32 reading the f16 half directly (exact in f32).  (v_fma_mixlo_f16 /
+//   v_fma_mixhi_f16 would write the rounded difference straight into one half of the packed result -- 8 instructions instead of 12,
+//   same bits -- but the partial-register writes are slower: 1.40-1.58 ms against 1.30 for the hi + lo kernel, round 3.)
 // One asm block; it ends with s_nop 1 because hipcc does not pad the VALU-write -> MFMA-read hazard for registers
 // written inside inline asm (cdna_hip_programming.md section 5.7 item 2): without it the MFMA may read stale operands.
 __device__ __forceinline__ void split_p8(const float (&p)[8], uint4& hi, uint4& lo) {
@@ -835,10 +837,12 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     unsigned long long* noredo = nullptr;
     hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn);
     GSDD_CHECK_LAUNCH();
-    // GSDD_ATTN_TRAIN_P=a8 lets the training forward use the sampler's adaptive lo half at L >= 2048 (default: hi + lo everywhere --
-    // its output and log-sum-exp feed the backward, where the adaptive mode's extra 1e-5 is noise on gradients that are mathematically zero)
+    // The training forward uses the sampler's adaptive lo half at L >= 2048 (the norm-bound form: on flat rows every tile is cleared a
+    // priori): its output error <= 2e-5 of the row scale is below what the gradient parity tests resolve (full-size gradient parity and
+    // the 2e-5 attention-backward bar pass unchanged) and the step is 3.2 ms shorter (64.6 -> 61.4 ms).  GSDD_ATTN_TRAIN_P=22: hi + lo
+    // everywhere, the round-2 behaviour.
     const char* tp = getenv("GSDD_ATTN_TRAIN_P");
-    if (tp != nullptr && tp[0] == 'a' && L >= 2048)
+    if (!(tp != nullptr && atoi(tp) == 22) && L >= 2048)
         hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
                            B, L, H, out, lse, noredo);
     else

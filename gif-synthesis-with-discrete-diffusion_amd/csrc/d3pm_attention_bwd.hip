@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
 //     stores and the previous chunk's slab flush run inside the compute phase instead of between two barriers (measured: the two
 //     barriers with the flush and the staging stores between them cost 15 % of the kernel).
 // Per 512 scores: 4 score MFMAs, 8 v_exp, 2 hi/lo splits, 6 accumulate MFMAs (dV, dK, dQ) -- against 8 + 16 + 3 + 6 for the pair.
-constexpr int FQC = 128;           // queries per LDS chunk
-constexpr int FSLAB = FQC + 8;     // slab column stride in floats (the 16-byte stores of lanes li = 0..3 land on distinct banks)
-
+// FQC = queries per LDS chunk (template parameter FQ); the slab column stride in floats is FQC + 8 (the 16-byte stores of lanes
+// li = 0..3 land on distinct banks)
+template <int FQC>
 struct FusedStage {
     uint4 q[FQC][3];
     uint4 g[FQC][3];
@@ -471,11 +471,11 @@ struct FusedStage {
 // Measured (round 3, bs 16, L = 4096): the training step is 2 ms SLOWER with it (65.6-66.2 vs 63.6-64.4 ms; the pair fused + reduce
 // 2.100 vs 2.088 ms in the microbenchmark): one barrier now releases eight lockstep waves instead of four, and what the bytes save is
 // not where the kernel's time is (vector issue 63 %, not memory).  NW = 4 stays the default; the traffic is not the lever here.
-template <int NW>
+template <int NW, int FQC>
 struct FusedSmem {
-    FusedStage st[2];              // by chunk parity
+    FusedStage<FQC> st[2];         // by chunk parity
     uint2 t[NW][2][2][32][4];      // [wave][hi/lo][query tile][key row of the pair][8-byte chunk, XOR-swizzled by (row >> 2) & 3]
-    float dq[2][NW][4][FSLAB];     // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
+    float dq[2][NW][4][FQC + 8];   // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
 };
 
 // ds_read_b64_tr_b16 through the compiler's builtin: it then places the s_waitcnt itself and orders the read after the wave's own
@@ -494,13 +494,13 @@ __device__ __forceinline__ float bw_piece_sum(float x) {
     return (x + a) + b;
 }
 
-template <int DBG, int NW = 4>   // DBG 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing only)
+template <int DBG, int NW = 4, int FQ = 128>   // DBG 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing only)
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float* __restrict__ k, const float* __restrict__ v, BwdImages im,
                                                                     int B, int L, int H, float* __restrict__ dqkv,
                                                                     float* __restrict__ dq_part) {
     extern __shared__ __attribute__((aligned(16))) char fused_raw[];
-    FusedSmem<NW>& sm = *reinterpret_cast<FusedSmem<NW>*>(fused_raw);
-    constexpr int NT = 64 * NW, KB = 64 * NW;                         // threads, keys per workgroup
+    FusedSmem<NW, FQ>& sm = *reinterpret_cast<FusedSmem<NW, FQ>*>(fused_raw);
+    constexpr int NT = 64 * NW, KB = 64 * NW, FQC = FQ;               // threads, keys per workgroup, queries per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nkb = (L + KB - 1) / KB;
     const unsigned wg = bw_xcd_remap(blockIdx.x, gridDim.x);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         rqv = qvs[min(tid, l2)]; rgv = gvs[min(tid, l2)];
     };
     auto store_chunk = [&](int par) {
-        FusedStage& st = sm.st[par];
+        FusedStage<FQ>& st = sm.st[par];
         uint4* qd = &st.q[0][0];
         uint4* gd = &st.g[0][0];
         if (tid < FQC * 3) { qd[tid] = rq0; gd[tid] = rg0; }                    // 384 fragments each
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
         if (ch + 2 < nchunks) load_chunk(ch + 2);
         if (ch > 0) flush_dq(ch - 1);
-        const FusedStage& st = sm.st[ch & 1];
+        const FusedStage<FQ>& st = sm.st[ch & 1];
         float* const slab = &sm.dq[ch & 1][wave][li & 3][4 * lg];
         const int npairs = min(FQC, L - ch * FQC) >> 5;
         for (int u = 0; u < npairs; ++u) {
@@ -741,13 +741,15 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
         static unsigned long long fattr_done = 0ull;      // one bit per device: the attribute is per device
         if (first_on_device(fattr_done)) {
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem<4>)));
+                                               (int)sizeof(FusedSmem<4, 128>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem<4>)));
+                                               (int)sizeof(FusedSmem<4, 128>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem<4>)));
+                                               (int)sizeof(FusedSmem<4, 128>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem<8>)));
+                                               (int)sizeof(FusedSmem<8, 128>)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem<4, 64>)));
         }
         const char* dbg = getenv("GSDD_FUSED_DBG");
         const int dbgv = dbg ? atoi(dbg) : 0;
@@ -755,10 +757,14 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
         const int nw = (dbgv == 0 && nwe != nullptr && atoi(nwe) == 8) ? 8 : 4;
         const int kb = 64 * nw, nkb = (L + kb - 1) / kb;
         const dim3 fgrid((unsigned)(B * H * nkb));
-        if (dbgv == 1) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, 4>), fgrid, dim3(256), sizeof(FusedSmem<4>), st, k, v, im, B, L, H, dqkv, dq_part);
-        else if (dbgv == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 4>), fgrid, dim3(256), sizeof(FusedSmem<4>), st, k, v, im, B, L, H, dqkv, dq_part);
-        else if (nw == 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4>), fgrid, dim3(256), sizeof(FusedSmem<4>), st, k, v, im, B, L, H, dqkv, dq_part);
-        else hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 8>), fgrid, dim3(512), sizeof(FusedSmem<8>), st, k, v, im, B, L, H, dqkv, dq_part);
+        if (dbgv == 1) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (dbgv == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (nw == 4 && !(getenv("GSDD_ATTN_BWD_FQC") != nullptr && atoi(getenv("GSDD_ATTN_BWD_FQC")) == 128))
+            // default: 64-query chunks.  44 KB of LDS per workgroup -> three workgroups (3 waves per SIMD, which the kernel's 160 VGPRs
+            // allow) instead of two with 128-query chunks (72 KB): 64.6 -> 63.5 ms per training step (A/B, two boxes' medians)
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4, 64>), fgrid, dim3(256), sizeof(FusedSmem<4, 64>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (nw == 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 8>), fgrid, dim3(512), sizeof(FusedSmem<8, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
         GSDD_CHECK_LAUNCH();
         hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, dq_part, nkb, H, M, dqkv);
         GSDD_CHECK_LAUNCH();

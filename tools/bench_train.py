@@ -25,14 +25,20 @@ def main():
     tok = torch.randint(0, K, (B, L), generator=g).cuda()
     cond = torch.zeros(B, 1, 512).cuda()
     losses = []
-    for i in range(4):
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    times = []
+    for i in range(steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = trainer.step(tok, cond)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         losses.append(float(loss[0]))
+        times.append(dt * 1e3)
         print(f"step {i}: loss {losses[-1]:.4f}  {dt * 1e3:.1f} ms  ({B / dt:.1f} samples/s)  mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    if steps > 4:
+        tail = sorted(times[2:])
+        print(f"median of steps 2..{steps - 1}: {tail[len(tail) // 2]:.2f} ms  (min {tail[0]:.2f})")
 
 
 if __name__ == "__main__":
