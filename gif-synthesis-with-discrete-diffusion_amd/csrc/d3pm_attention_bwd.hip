@@ -446,18 +446,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
 // lane (as the dK/dV kernel does), and gets dQ out of the same dS:
 //   * dS (bf16 hi / lo, 8 bytes per lane and 16-query tile) crosses a wave-private LDS image [32 keys][16 queries] once and is read
 //     back transposed with ds_read_b64_tr_b16: 4 keys x 16 queries per 16-lane group arrive query-major, which is exactly the A
-//     fragment of   dQ[query][col] += dS^T[query][key] . [k1 | k2 | k3][key][col]   (one v_mfma_f32_16x16x32_bf16 per 32 keys);
-//   * a wave sums dQ over its 64 keys in the accumulator, adds the three K pieces across lanes (two DPP adds) and stores the 4
-//     columns to its own slab [column][query] (one ds_write_b128 per 16-query tile; LDS float atomics into one shared tile cost
-//     ~100 cycles each here); after each 128-query chunk the four slabs (256 keys) are added and written out with plain stores to
+//     fragment layout of a v_mfma_f32_16x16x32_bf16 over 32 keys;
+//   * the product is taken transposed, dQ^T[4 d + piece][query] (A = the wave's K image with its columns reordered, B = the dS
+//     fragment -- both operands of a 16x16x32 MFMA have the same lane layout, so the transposed read serves either side): a wave
+//     sums dQ over its 64 keys in the accumulator, the three K pieces of a column are registers 0..2 of one lane (two in-lane adds),
+//     and each lane stores one float per 16-query tile to the wave's own slab [column][query] (LDS float atomics into one shared tile
+//     cost ~100 cycles each here); after each query chunk the four slabs (256 keys) are added and written out with plain stores to
 //     partial[key block][head][row][4]; attn_bwd_dq_reduce_kernel adds the L/256 partials (fixed order: bitwise reproducible,
 //     unlike float atomics, and ~4x cheaper per byte -- MI355X_MICROARCH.md "Global float atomics").
 //   * ONE barrier per chunk: the query-side staging and the slabs are double-buffered by chunk parity, so the next chunk's staging
 //     stores and the previous chunk's slab flush run inside the compute phase instead of between two barriers (measured: the two
 //     barriers with the flush and the staging stores between them cost 15 % of the kernel).
 // Per 512 scores: 4 score MFMAs, 8 v_exp, 2 hi/lo splits, 6 accumulate MFMAs (dV, dK, dQ) -- against 8 + 16 + 3 + 6 for the pair.
-// FQC = queries per LDS chunk (template parameter FQ); the slab column stride in floats is FQC + 8 (the 16-byte stores of lanes
-// li = 0..3 land on distinct banks)
+// FQC = queries per LDS chunk (template parameter FQ); the slab column stride in floats is FQC + 16 (the 4-byte stores of lane
+// groups 0 / 1 -- columns 0 / 1 -- land on banks 0..15 / 16..31)
 template <int FQC>
 struct FusedStage {
     uint4 q[FQC][3];
@@ -475,7 +477,8 @@ template <int NW, int FQC>
 struct FusedSmem {
     FusedStage<FQC> st[2];         // by chunk parity
     uint2 t[NW][2][2][32][4];      // [wave][hi/lo][query tile][key row of the pair][8-byte chunk, XOR-swizzled by (row >> 2) & 3]
-    float dq[2][NW][4][FQC + 8];   // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
+                                   // (hi and lo of a chunk side by side, stored with one ds_write_b128 instead of two b64: 2 % slower)
+    float dq[2][NW][4][FQC + 16];  // [chunk parity][wave][column][query]: each wave's own sum over its 64 keys
 };
 
 // ds_read_b64_tr_b16 through the compiler's builtin: it then places the s_waitcnt itself and orders the read after the wave's own
@@ -522,13 +525,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         kfrag[j] = bw_col_frag(ks, lg, bw_ones_frag());
         vfrag[j] = bw_col_frag(vs, lg, bw_ones_frag());
     }
-    // accumulate image of this wave's keys (B operand of the dQ product), one 32-key pair-tile per jp; a pair-tile past the end of
+    // accumulate image of this wave's keys, one 32-key pair-tile per jp: the A operand of the TRANSPOSED dQ product
+    //   dQ^T[4 d + piece][query] += K^T[4 d + piece][key] . dS^T[key][query],
+    // i.e. lane li = 4 d + piece takes image column piece * 4 + d.  Row 4 lg + r of the output sits in register r of lane group lg, so a
+    // lane group is one column d of dQ and its registers are the three bf16 pieces of K: the piece sum is two in-lane adds (the
+    // untransposed product had the pieces on 12 different lanes: 16 DPP moves + 8 packed adds per pair-tile, 11 % of the kernel); a pair-tile past the end of
     // the sequence (L % 256 != 0; L % 32 == 0) gets a zero image: its clamped keys give finite dS, times zero they add nothing
     uint4 kvb[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         const int kp0 = min(k0 + 32 * jp, L - 32);
-        kvb[jp] = im.kv[((hrow0 + kp0) >> 5) * 64 + lg * 16 + li];
+        kvb[jp] = im.kv[((hrow0 + kp0) >> 5) * 64 + lg * 16 + (li & 3) * 4 + (li >> 2)];
         if (k0 + 32 * jp >= L) kvb[jp] = make_uint4(0u, 0u, 0u, 0u);
     }
 
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         if (ch + 2 < nchunks) load_chunk(ch + 2);
         if (ch > 0) flush_dq(ch - 1);
         const FusedStage<FQ>& st = sm.st[ch & 1];
-        float* const slab = &sm.dq[ch & 1][wave][li & 3][4 * lg];
+        float* const slab = &sm.dq[ch & 1][wave][lg][li];
         const int npairs = min(FQC, L - ch * FQC) >> 5;
         for (int u = 0; u < npairs; ++u) {
             const bf16x8 qa0 = bw_frag(st.q[32 * u + li][piece]), qa1 = bw_frag(st.q[32 * u + 16 + li][piece]);
@@ -641,24 +648,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
                     const uint2 l0a = lds_read_tr16(tr0 + T_HL), l0b = lds_read_tr16(tr0 + T_HL + T_ROW16);
                     const uint2 l1a = lds_read_tr16(tr0 + T_HL + T_TILE), l1b = lds_read_tr16(tr0 + T_HL + T_TILE + T_ROW16);
                     const bf16x8 kb = bw_frag(kvb[jp]);
-                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(h0a.x, h0a.y, h0b.x, h0b.y)), kb, dq0, 0, 0, 0);
-                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(h1a.x, h1a.y, h1b.x, h1b.y)), kb, dq1, 0, 0, 0);
-                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l0a.x, l0a.y, l0b.x, l0b.y)), kb, dq0, 0, 0, 0);
-                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw_frag(make_uint4(l1a.x, l1a.y, l1b.x, l1b.y)), kb, dq1, 0, 0, 0);
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, bw_frag(make_uint4(h0a.x, h0a.y, h0b.x, h0b.y)), dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, bw_frag(make_uint4(h1a.x, h1a.y, h1b.x, h1b.y)), dq1, 0, 0, 0);
+                    dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, bw_frag(make_uint4(l0a.x, l0a.y, l0b.x, l0b.y)), dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, bw_frag(make_uint4(l1a.x, l1a.y, l1b.x, l1b.y)), dq1, 0, 0, 0);
                 }
             }
-            // the wave's 64 keys are summed; the three K pieces (columns li, li + 4, li + 8) are added across lanes, and lanes li < 4
-            // store queries 4 lg .. 4 lg + 3 of both 16-query tiles to the wave's slab, column li
+            // the wave's 64 keys are summed; lane (li, lg) holds column lg of query li of both 16-query tiles as three pieces in
+            // registers 0..2 (register 3 is the image's zero column), added in the order (k1 + k2) + k3 as before
             if (DBG >= 1) {
                 if (dq0[0] + dq1[0] == 123.456f) sm.dq[0][wave][0][0] = 1.f;    // keep the products alive
             } else {
-                float4 a0, a1;
-                a0.x = bw_piece_sum(dq0[0]); a0.y = bw_piece_sum(dq0[1]); a0.z = bw_piece_sum(dq0[2]); a0.w = bw_piece_sum(dq0[3]);
-                a1.x = bw_piece_sum(dq1[0]); a1.y = bw_piece_sum(dq1[1]); a1.z = bw_piece_sum(dq1[2]); a1.w = bw_piece_sum(dq1[3]);
-                if (li < 4) {
-                    *reinterpret_cast<float4*>(slab + 32 * u) = a0;
-                    *reinterpret_cast<float4*>(slab + 32 * u + 16) = a1;
-                }
+                slab[32 * u] = (dq0[0] + dq0[1]) + dq0[2];
+                slab[32 * u + 16] = (dq1[0] + dq1[1]) + dq1[2];
             }
         }
         __syncthreads();
