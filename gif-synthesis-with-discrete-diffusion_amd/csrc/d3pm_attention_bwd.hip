@@ -177,8 +177,10 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
     bw_row_pieces(gs, pa, pb);
     im.gp[row * 3 + 0] = pa; im.gp[row * 3 + 1] = pb; im.gp[row * 3 + 2] = bw_slot_frag(-delta);
     bw_store_vformat(ks, row, im.kv);
-    bw_store_vformat(qr, row, im.qv);
-    bw_store_vformat(gs, row, im.gv);
+    if (score_kv) {          // accumulate images of Q and dO: the fused kernel reads them out of the score-row images (transposed LDS reads)
+        bw_store_vformat(qr, row, im.qv);
+        bw_store_vformat(gs, row, im.gv);
+    }
 }
 
 __device__ __forceinline__ unsigned bw_xcd_remap(unsigned wg, unsigned nwg) {
@@ -462,10 +464,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
 // groups 0 / 1 -- columns 0 / 1 -- land on banks 0..15 / 16..31)
 template <int FQC>
 struct FusedStage {
-    uint4 q[FQC][3];
-    uint4 g[FQC][3];
-    uint4 qv[FQC / 32][4][16];
-    uint4 gv[FQC / 32][4][16];
+    uint4 q[FQC][3];               // score-row image of c Q: [x1 | x2] [x3 | x1] [-lse slots]; its first 32 bytes are also the 16 columns
+    uint4 g[FQC][3];               // [x1 | x2 | x3 | x1] the accumulate products read transposed (the fourth column group is ignored)
 };
 // NW waves per workgroup = NW * 64 keys.  NW = 8 (GSDD_ATTN_BWD_NW=8) lets the query-side chunk staged in LDS serve 512 keys instead
 // of 256: the staging traffic per key and the number of partial dQ copies (one per workgroup and query) halve -- 307 -> 154 MB written
@@ -540,17 +540,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
     }
 
     const int nchunks = (L + FQC - 1) / FQC;
-    uint4 rq0, rq1, rg0, rg1, rqv, rgv;
+    uint4 rq0, rq1, rg0, rg1;
     auto load_chunk = [&](int ch) {
         const int rows = min(FQC, L - ch * FQC);                      // multiple of 32
         const uint4* qs = im.qp + (hrow0 + (int64_t)ch * FQC) * 3;
         const uint4* gs = im.gp + (hrow0 + (int64_t)ch * FQC) * 3;
-        const uint4* qvs = im.qv + ((hrow0 + (int64_t)ch * FQC) >> 5) * 64;
-        const uint4* gvs = im.gv + ((hrow0 + (int64_t)ch * FQC) >> 5) * 64;
-        const int l3 = rows * 3 - 1, l2 = rows * 2 - 1;               // unconditional, clamped loads (see the dQ kernel)
+        const int l3 = rows * 3 - 1;                                  // unconditional, clamped loads (see the dQ kernel)
         rq0 = qs[min(tid, l3)]; rg0 = gs[min(tid, l3)];
         if (NT < FQC * 3) { rq1 = qs[min(tid + NT, l3)]; rg1 = gs[min(tid + NT, l3)]; }
-        rqv = qvs[min(tid, l2)]; rgv = gvs[min(tid, l2)];
     };
     auto store_chunk = [&](int par) {
         FusedStage<FQ>& st = sm.st[par];
@@ -558,10 +555,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         uint4* gd = &st.g[0][0];
         if (tid < FQC * 3) { qd[tid] = rq0; gd[tid] = rg0; }                    // 384 fragments each
         if (NT < FQC * 3 && tid < FQC * 3 - NT) { qd[tid + NT] = rq1; gd[tid + NT] = rg1; }
-        if (tid < FQC * 2) {                                                    // 256 fragments each
-            (&st.qv[0][0][0])[tid] = rqv;
-            (&st.gv[0][0][0])[tid] = rgv;
-        }
     };
     // partial dQ of chunk `ch` (this workgroup's keys = its waves' slabs) -> dq_part[kblk][h][row][4]; thread = (query, column pair)
     auto flush_dq = [&](int ch) {
@@ -610,7 +603,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         for (int u = 0; u < npairs; ++u) {
             const bf16x8 qa0 = bw_frag(st.q[32 * u + li][piece]), qa1 = bw_frag(st.q[32 * u + 16 + li][piece]);
             const bf16x8 ga0 = bw_frag(st.g[32 * u + li][piece]), ga1 = bw_frag(st.g[32 * u + 16 + li][piece]);
-            const bf16x8 qvb = bw_frag(st.qv[u][lg][li]), gvb = bw_frag(st.gv[u][lg][li]);
+            // accumulate-side fragments (B operand of dK += dS^T Q, dV += P^T dO): lane (lg, column li) needs column li of queries
+            // 4 lg .. 4 lg + 3 of both 16-query tiles -- the transposed read of the row-major score image (16 lanes point at 4 rows x
+            // 4 chunks of 4 columns and get one column of the 4 rows each); round 2 staged a second, pre-transposed image for this
+            const uint2* const qt = reinterpret_cast<const uint2*>(&st.q[32 * u + 4 * lg + (li >> 2)][0]) + (li & 3);
+            const uint2* const gt = reinterpret_cast<const uint2*>(&st.g[32 * u + 4 * lg + (li >> 2)][0]) + (li & 3);
+            const uint2 qt0 = lds_read_tr16(qt), qt1 = lds_read_tr16(qt + 16 * 6), gt0 = lds_read_tr16(gt), gt1 = lds_read_tr16(gt + 16 * 6);
+            const bf16x8 qvb = bw_frag(make_uint4(qt0.x, qt0.y, qt1.x, qt1.y)), gvb = bw_frag(make_uint4(gt0.x, gt0.y, gt1.x, gt1.y));
             f32x4 dq0 = zero, dq1 = zero;
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
             const int ki = k0 + 16 * j + 4 * lg + e;
             if (li < 4 && ki < L) {
                 float* dst = dqkv + ((int64_t)b * L + ki) * (3 * H * 4);
-                dst[H * 4 + h * 4 + li] = 0.5f * ((ak + ak1) + ak2);
+                dst[H * 4 + h * 4 + li] = 0.6931471805599453f * ((ak + ak1) + ak2);      // 1/2 dS^T Q = (1 / (2 c)) dS^T (c Q), c = log2(e) / 2
                 dst[2 * H * 4 + h * 4 + li] = (av + av1) + av2;
             }
         }
