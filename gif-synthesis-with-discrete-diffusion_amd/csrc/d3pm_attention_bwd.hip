@@ -156,8 +156,11 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
     const int h = (int)(row / M);
     const int64_t m = row - (int64_t)h * M;
     const float4 rq = *reinterpret_cast<const float4*>(q + row * 4);
-    const float4 rk = *reinterpret_cast<const float4*>(k + row * 4);
-    const float4 rv = *reinterpret_cast<const float4*>(v + row * 4);
+    float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), rv = rk;          // K and V images: the two-kernel variant only (the fused kernel
+    if (score_kv) {                                                   // splits its own keys)
+        rk = *reinterpret_cast<const float4*>(k + row * 4);
+        rv = *reinterpret_cast<const float4*>(v + row * 4);
+    }
     const float4 rg = *reinterpret_cast<const float4*>(dO + m * (H * 4) + h * 4);
     const float4 ro = *reinterpret_cast<const float4*>(o + m * (H * 4) + h * 4);
     const float delta = (rg.x * ro.x + rg.y * ro.y) + (rg.z * ro.z + rg.w * ro.w);
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
     im.qp[row * 3 + 0] = pa; im.qp[row * 3 + 1] = pb; im.qp[row * 3 + 2] = bw_slot_frag(-lse[row]);
     bw_row_pieces(gs, pa, pb);
     im.gp[row * 3 + 0] = pa; im.gp[row * 3 + 1] = pb; im.gp[row * 3 + 2] = bw_slot_frag(-delta);
-    bw_store_vformat(ks, row, im.kv);
-    if (score_kv) {          // accumulate images of Q and dO: the fused kernel reads them out of the score-row images (transposed LDS reads)
+    if (score_kv) {          // accumulate images: the fused kernel reads them out of the score-row images (transposed LDS reads)
+        bw_store_vformat(ks, row, im.kv);
         bw_store_vformat(qr, row, im.qv);
         bw_store_vformat(gs, row, im.gv);
     }
@@ -524,18 +527,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
         const float ks[4] = {kk.x, kk.y, kk.z, kk.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
         kfrag[j] = bw_col_frag(ks, lg, bw_ones_frag());
         vfrag[j] = bw_col_frag(vs, lg, bw_ones_frag());
+        if (j == lg) {
+            // row-major image of key 16 lg + li in the wave's (still unused) transpose buffer: position 4 d + piece = piece of k[d]
+            uint2* row = &sm.t[wave][0][0][0][0] + (16 * lg + li) * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t a, b, c;
+                bw_split3(ks[d], a, b, c);
+                row[d] = make_uint2(a | (b << 16), c);
+            }
+        }
     }
     // accumulate image of this wave's keys, one 32-key pair-tile per jp: the A operand of the TRANSPOSED dQ product
     //   dQ^T[4 d + piece][query] += K^T[4 d + piece][key] . dS^T[key][query],
-    // i.e. lane li = 4 d + piece takes image column piece * 4 + d.  Row 4 lg + r of the output sits in register r of lane group lg, so a
+    // read transposed out of the row-major image above (lane li = 4 d + piece gets position li of keys 4 lg .. 4 lg + 3 of both 16-key
+    // tiles; LDS instructions of a wave execute in order, so the rows written by other lanes are in place).  Row 4 lg + r of the output sits in register r of lane group lg, so a
     // lane group is one column d of dQ and its registers are the three bf16 pieces of K: the piece sum is two in-lane adds (the
     // untransposed product had the pieces on 12 different lanes: 16 DPP moves + 8 packed adds per pair-tile, 11 % of the kernel); a pair-tile past the end of
     // the sequence (L % 256 != 0; L % 32 == 0) gets a zero image: its clamped keys give finite dS, times zero they add nothing
     uint4 kvb[2];
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
-        const int kp0 = min(k0 + 32 * jp, L - 32);
-        kvb[jp] = im.kv[((hrow0 + kp0) >> 5) * 64 + lg * 16 + (li & 3) * 4 + (li >> 2)];
+        const uint2* kt = &sm.t[wave][0][0][0][0] + (32 * jp + 4 * lg + (li >> 2)) * 4 + (li & 3);
+        const uint2 kt0 = lds_read_tr16(kt), kt1 = lds_read_tr16(kt + 16 * 4);
+        kvb[jp] = make_uint4(kt0.x, kt0.y, kt1.x, kt1.y);
         if (k0 + 32 * jp >= L) kvb[jp] = make_uint4(0u, 0u, 0u, 0u);
     }
 
