@@ -52,17 +52,18 @@ def build_models(args, device):
     return dm.to(device).eval(), vq.to(device).eval(), L
 
 
-def profile_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest profiles/r*_pmc_traffic.csv that lists it (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes, committed with the round; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
-    MI355X_MICROARCH.md).  -> (bytes, file name) or (None, None): the number is read, never typed in."""
+def profile_traffic(kernel, grid):
+    """HBM bytes per launch of `kernel` at `grid` workgroups from the newest profiles/r*_pmc_traffic.csv that lists it (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes, committed with the round, one row per kernel and grid size -- tools/make_traffic_csv.py;
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md).  -> (bytes, file name) or (None, None):
+    the number is read, never typed in."""
     import csv
     import glob
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.csv")), reverse=True):
         with open(f) as fh:
             rows = [r for r in csv.DictReader(l for l in fh if not l.startswith("#"))]
         for r in rows:
-            if r["kernel"].replace(" ", "") == kernel.replace(", ", ";").replace(" ", ""):
+            if r["kernel"].replace(" ", "") == kernel.replace(", ", ";").replace(" ", "") and int(r.get("grid_workgroups", grid)) == grid:
                 return (2 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) * 1024, os.path.basename(f)
     return None, None
 
@@ -119,7 +120,7 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
     ms, n = mean_ms("attention")
     flops = 16.0 * L * L * H * B2
     tf = flops / (ms * 1e-3) / 1e12
-    traffic, src = profile_traffic(kernel) if (B2, L, H) == (32, 4096, 16) else (None, None)
+    traffic, src = profile_traffic(kernel, B2 * H * ((L + 255) // 256)) if (B2, L, H) == (32, 4096, 16) else (None, None)
     roof = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src, "ms_per_launch": round(ms, 4),
             "launches_timed": n, "flops_per_launch": flops,

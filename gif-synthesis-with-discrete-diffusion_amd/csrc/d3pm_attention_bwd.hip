@@ -766,19 +766,26 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
                                                (int)sizeof(FusedSmem<8, 128>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sizeof(FusedSmem<4, 64>)));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)sizeof(FusedSmem<4, 96>)));
         }
         const char* dbg = getenv("GSDD_FUSED_DBG");
         const int dbgv = dbg ? atoi(dbg) : 0;
+        const char* fqe = getenv("GSDD_ATTN_BWD_FQC");                // A/B switch (read per call): queries per LDS chunk, 96 (default), 64, 128
+        const int fqc = fqe != nullptr ? atoi(fqe) : 96;
         const char* nwe = getenv("GSDD_ATTN_BWD_NW");                 // A/B switch (read per call): waves per workgroup, 4 (default) or 8
         const int nw = (dbgv == 0 && nwe != nullptr && atoi(nwe) == 8) ? 8 : 4;
         const int kb = 64 * nw, nkb = (L + kb - 1) / kb;
         const dim3 fgrid((unsigned)(B * H * nkb));
         if (dbgv == 1) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
         else if (dbgv == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
-        else if (nw == 4 && !(getenv("GSDD_ATTN_BWD_FQC") != nullptr && atoi(getenv("GSDD_ATTN_BWD_FQC")) == 128))
-            // default: 64-query chunks.  44 KB of LDS per workgroup -> three workgroups (3 waves per SIMD, which the kernel's 160 VGPRs
-            // allow) instead of two with 128-query chunks (72 KB): 64.6 -> 63.5 ms per training step (A/B, two boxes' medians)
+        else if (nw == 4 && fqc == 64)
             hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4, 64>), fgrid, dim3(256), sizeof(FusedSmem<4, 64>), st, k, v, im, B, L, H, dqkv, dq_part);
+        else if (nw == 4 && fqc != 128)
+            // default: 96-query chunks.  49 KB of LDS per workgroup -> three workgroups per CU (3 waves per SIMD, which the kernel's 156
+            // VGPRs allow) where 128-query chunks (58 KB) fit two; 64-query chunks (38 KB) fit three as well but pay a third more chunk
+            // barriers: 1.995 / 1.94 / 1.92 ms for 128 / 64 / 96 (microbenchmark incl. pre-split and reduction, one box)
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4, 96>), fgrid, dim3(256), sizeof(FusedSmem<4, 96>), st, k, v, im, B, L, H, dqkv, dq_part);
         else if (nw == 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
         else hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 8>), fgrid, dim3(512), sizeof(FusedSmem<8, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
         GSDD_CHECK_LAUNCH();

@@ -285,18 +285,22 @@ def test_rccl_initialises_and_carries_the_bucketed_exchange_on_one_gpu(G):
 
 
 # ----------------------------------------------------------------------------- attention backward kernels vs fp64 autograd
-@pytest.mark.parametrize("mode", ["fused", "split", "valu"])
+@pytest.mark.parametrize("mode", ["fused", "fused_q64", "fused_q128", "fused_w8", "split", "valu"])
 @pytest.mark.parametrize("B,L,scale", [(2, 64, 1.0), (1, 320, 1.5), (1, 1024, 1.0), (2, 96, 3.0), (2, 544, 1.0)])
 def test_attention_backward_matches_fp64_autograd(G, B, L, scale, mode, monkeypatch):
     """dq | dk | dv of softmax(q k^T / 2) v for head dim 4 against torch.autograd in fp64: the fused matrix-pipe kernel (one pass,
-    dS through an LDS transpose, partial dQ per 256-key block + reduction), the two-kernel matrix-pipe variant
-    (GSDD_ATTN_BWD_SPLIT) and the VALU kernels (no workspace).  L = 320 / 544 cover partial key blocks and query chunks (544 =
-    2 key blocks + 32, 4 query chunks + 32), scale 3 peaky attention."""
+    dS through an LDS transpose, partial dQ per 256-key block + reduction; default 96-query chunks, and the selectable 64- / 128-query
+    chunks and 8-wave workgroups), the two-kernel matrix-pipe variant (GSDD_ATTN_BWD_SPLIT) and the VALU kernels (no workspace).
+    L = 320 / 544 cover partial key blocks and query chunks (544 = 2 key blocks + 32, 5 query chunks + 64), scale 3 peaky attention."""
     valu = mode == "valu"
+    for name in ("GSDD_ATTN_BWD_SPLIT", "GSDD_ATTN_BWD_FQC", "GSDD_ATTN_BWD_NW"):
+        monkeypatch.delenv(name, raising=False)
     if mode == "split":
         monkeypatch.setenv("GSDD_ATTN_BWD_SPLIT", "1")
-    else:
-        monkeypatch.delenv("GSDD_ATTN_BWD_SPLIT", raising=False)
+    elif mode in ("fused_q64", "fused_q128"):
+        monkeypatch.setenv("GSDD_ATTN_BWD_FQC", mode[7:])
+    elif mode == "fused_w8":
+        monkeypatch.setenv("GSDD_ATTN_BWD_NW", "8")
     H = 16
     g = torch.Generator().manual_seed(9)
     q = (torch.randn(B, H, L, 4, generator=g) * scale).double().requires_grad_(True)

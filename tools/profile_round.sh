@@ -22,11 +22,12 @@ export GSDD_BENCH_SCALES=0.05
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$O/sq_flat" -- python3 "$R/tools/bench_kernels.py" attn > "$O/sq_flat.log" 2>&1
 export GSDD_BENCH_SCALES=1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$O/sq_x1" -- python3 "$R/tools/bench_kernels.py" attn > "$O/sq_x1.log" 2>&1
-export GSDD_BENCH_SCALES=0.05 GSDD_BENCH_PMODES=a8,22
+export GSDD_BENCH_SCALES=0.05 GSDD_BENCH_PMODES=a8,22 GSDD_BENCH_BWD_VARIANTS=fused
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 "$R/tools/bench_kernels.py" attn step attnbwd nearest > "$O/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 "$R/tools/bench_kernels.py" attn step attnbwd nearest > "$O/write.log" 2>&1
-unset GSDD_BENCH_SCALES GSDD_BENCH_PMODES
-for d in sq_flat sq_x1 fetch write; do python3 "$R/tools/summarize_pmc.py" "$O/$d" d3pm_attention_v4 d3pm_step attn_bwd nearest_code > "$O/$d.summary.csv"; done
+unset GSDD_BENCH_SCALES GSDD_BENCH_PMODES GSDD_BENCH_BWD_VARIANTS
+for d in sq_flat sq_x1; do python3 "$R/tools/summarize_pmc.py" "$O/$d" d3pm_attention_v4 > "$O/$d.summary.csv"; done
+python3 "$R/tools/make_traffic_csv.py" "$O/fetch" "$O/write" d3pm_attention_v4 d3pm_step attn_bwd nearest_code > "$O/traffic.csv"
 for d in bench train nearest; do f=$(find "$O/$d" -name "*kernel_stats.csv" | head -1); python3 "$R/tools/summarize_prof.py" "$f" 16 > "$O/$d.summary.csv"; done
 python3 "$R/tools/summarize_trace.py" "$O/bench" d3pm_ > "$O/bench.bygrid.csv"
 python3 "$R/tools/summarize_trace.py" "$O/nearest" nearest_code code_norm > "$O/nearest.bygrid.csv"
