@@ -146,9 +146,16 @@ __device__ __forceinline__ void kv_image_store_v(const float (&vs)[4], int64_t r
 // Per-tile key norms of the attention workspace: knorm[(h*M + b*L + key) >> 5] = an upper bound of max ||k|| over the 32 keys of
 // that pair-tile (f32, rounded up).  With the wave's ||q|| it bounds every score of a (query, pair-tile) by Cauchy-Schwarz, which is
 // how the attention kernel proves "no probability of this tile can matter" without looking at the scores (d3pm_attention.hip).
-// Workspace layout (gsdd_d3pm_attention_workspace_bytes): K image 32 B per (key, head) | V image 32 B | knorm 4 B per 32 keys.
+// ksum[(h*M + b*L + key) >> 5] = the sum of the 32 keys of that pair-tile (float4, fixed summation tree: bitwise reproducible): the
+// attention kernel adds the tiles of a (b, h) to the mean key, which gives it a lower bound of every FINAL row sum before it has seen a
+// key (Jensen: log2 sum_j 2^s_j >= log2 L + mean_j s_j = log2 L + q . kmean).
+// Workspace layout (gsdd_d3pm_attention_workspace_bytes): K image 32 B per (key, head) | V image 32 B | ksum 16 B per 32 keys | knorm 4 B
+// per 32 keys.
+__host__ __device__ __forceinline__ float4* kv_image_ksum(void* workspace, int64_t rows) {
+    return reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + rows * 64);
+}
 __host__ __device__ __forceinline__ float* kv_image_knorm(void* workspace, int64_t rows) {
-    return reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + rows * 64);
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + rows * 64 + ((rows + 31) / 32) * 16);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_max(float v) {
@@ -171,6 +178,18 @@ __device__ __forceinline__ float row16_min(float v) {
     v = dpp_min<0x141>(v);
     return dpp_min<0x140>(v);
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 32 lanes of a half (same exchange pattern as the maxima: every lane ends with the same bits)
+__device__ __forceinline__ float half32_sum(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    return v + __shfl_xor(v, 16);
+}
 // ||k|| bound of one pair-tile from per-lane squared norms: lanes of a 32-lane half hold the 32 keys; lane 0 of the half gets it
 __device__ __forceinline__ float half32_norm_bound(float n2) {
     float v = row16_max(n2);
@@ -178,13 +197,18 @@ __device__ __forceinline__ float half32_norm_bound(float n2) {
     return sqrtf(v) * 1.000001f + 1e-30f;
 }
 // fused layer kernels: lane (li = row of the 32-row group, h) holds k of heads 8 (q >> 2) + 2 (q & 3) + h in o[q]
-__device__ __forceinline__ void kv_image_store_knorm(const float4 (&o)[8], int h, int li, int64_t grp, int64_t M, float* knorm) {
+__device__ __forceinline__ void kv_image_store_knorm(const float4 (&o)[8], int h, int li, int64_t grp, int64_t M, float* knorm,
+                                                     float4* ksum) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const float n2 = (o[q].x * o[q].x + o[q].y * o[q].y) + (o[q].z * o[q].z + o[q].w * o[q].w);
         const float nb = half32_norm_bound(n2);
+        const float4 sk = make_float4(half32_sum(o[q].x), half32_sum(o[q].y), half32_sum(o[q].z), half32_sum(o[q].w));
         const int hd = 8 * (q >> 2) + 2 * (q & 3) + h;
-        if (li == 0) knorm[(int64_t)hd * (M >> 5) + grp] = nb;
+        if (li == 0) {
+            knorm[(int64_t)hd * (M >> 5) + grp] = nb;
+            ksum[(int64_t)hd * (M >> 5) + grp] = sk;
+        }
     }
 }
 

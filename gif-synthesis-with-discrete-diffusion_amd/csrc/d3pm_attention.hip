@@ -374,7 +374,7 @@ __device__ __forceinline__ bool any_gt_h8(const uint4& hi, uint32_t thr2) {
 //                             cols = [v1 | v2*2^11 | v3*2^22 | 1 | 0 0 0]
 __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                              int64_t rows, uint4* __restrict__ kp, uint4* __restrict__ vp,
-                                                             float* __restrict__ knorm) {
+                                                             float* __restrict__ knorm, float4* __restrict__ ksum) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;       // row = h*M + b*L + key (L % 32 == 0)
     if (row >= rows) return;                                          // rows % 32 == 0: whole 32-lane halves leave together
     const float4 rk = *reinterpret_cast<const float4*>(k + row * 4);
@@ -383,7 +383,11 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
     kv_image_store_k(ks, row, kp);
     kv_image_store_v(vs, row, vp);
     const float nb = half32_norm_bound((rk.x * rk.x + rk.y * rk.y) + (rk.z * rk.z + rk.w * rk.w));
-    if ((threadIdx.x & 31) == 0) knorm[row >> 5] = nb;
+    const float4 sk = make_float4(half32_sum(rk.x), half32_sum(rk.y), half32_sum(rk.z), half32_sum(rk.w));
+    if ((threadIdx.x & 31) == 0) {
+        knorm[row >> 5] = nb;
+        ksum[row >> 5] = sk;
+    }
 }
 
 // One pass over the pair-tiles of a staged chunk for the wave's 4 x 16 queries.  MODE 1: P = hi + lo; 0: hi only; 2: hi, and lo only
@@ -461,7 +465,8 @@ __device__ __forceinline__ int attn_tiles(const AttnSmem4<KC4>& sm, int buf, int
 template <int KC4, int PM = 1>
 __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __restrict__ q, const uint4* __restrict__ kp,
                                                                 const uint4* __restrict__ vp, const float* __restrict__ knorm,
-                                                                int B, int L, int H, float* __restrict__ out,
+                                                                const float4* __restrict__ ksum, int B, int L, int H,
+                                                                float* __restrict__ out,
                                                                 float* __restrict__ lse, unsigned long long* __restrict__ redo) {
     __shared__ AttnSmem4<KC4> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -480,6 +485,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     const uint4* kph = kp + ((int64_t)h * M + (int64_t)b * L) * 2;        // 2 uint4 per key
     const uint4* vph = vp + (((int64_t)h * M + (int64_t)b * L) >> 5) * 64; // 64 uint4 per 32-key pair-tile
     const float* knh = knorm + (((int64_t)h * M + (int64_t)b * L) >> 5);   // one float per 32-key pair-tile
+    const float4* ksh = ksum + (((int64_t)h * M + (int64_t)b * L) >> 5);  // one float4 per 32-key pair-tile
     const int li = lane & 15, lg = lane >> 4;
     const int q0 = qblk * 256 + wave * 64;
 
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     const float qscale = 0.5f * 1.4426950408889634f;
     uint4 qfrag[4];
     float rqn[4];                               // PM >= 2: 1 / (||q'|| of query li, rounded up): the score bound's slope
+    float4 qsv[4];                              // PM >= 2: q' of query li (log2 domain), for the row-sum lower bound
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int qi = q0 + 16 * j + li;
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         qfrag[j] = lg == 0 ? f0 : (lg == 1 ? f1 : (lg == 2 ? f2 : make_uint4(0u, 0u, 0u, 0u)));
         // 1.0001: the split products, the norms' own rounding and v_rcp/v_log/v_sqrt (1 ulp each) are all below 2^-20 relative
         rqn[j] = 1.0f / (sqrtf((qs[0] * qs[0] + qs[1] * qs[1]) + (qs[2] * qs[2] + qs[3] * qs[3])) * 1.0001f + 1e-30f);
+        qsv[j] = make_float4(qs[0], qs[1], qs[2], qs[3]);
     }
 
     const int nchunks = (L + KC4 - 1) / KC4;
@@ -563,8 +571,9 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     // that a chunk runs the adaptive loop, and if fewer than half of its tiles could skip the lo half the wave goes back to the plain
     // hi + lo loop (no per-tile test, one basic block per pair-tile) and probes again later, each time twice as much later (a row
     // that was not flat after 384 keys seldom becomes flat): chunks 1, 6, 15, 32, ...
-    bool adapt = false;
+    bool adapt = PM >= 2;                       // (the row-sum lower bound below gives the first chunk a threshold too)
     int probe = 1, backoff = 4;
+    float jb[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // log2 of a lower bound of query li's FINAL row sum (absolute scale)
     float kbj[4] = {0.f, 0.f, 0.f, 0.f};        // the bound's per-sub-tile numbers (wave-uniform values); 0 = clears nothing
     int kb_next = 1, kb_gap = 1;                // chunk of the next recomputation, and the gap after it
     if (PM >= 2) {
@@ -578,8 +587,26 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         for (int i = lane; i < (L >> 5); i += 64) knm = fmaxf(knm, knh[i]);
         knm = wave_max(knm) * 1.0001f;
         const float budget = log2f((float)L) - (float)PM - 0.02f;
+        // Sharper, and per query: Jensen -- log2 sum_j 2^(q'.k_j) >= log2(L) + q'.kmean, kmean from the per-tile key sums the K image's
+        // producer left next to the tile norms (fixed summation order: the same bits in every workgroup and every run).  It is within
+        // sigma^2 / 2 nats of the true log row sum for scores of spread sigma, where the bound above is off by ||q'|| (KNmax + ||kmean||).
+        // It replaces the a priori row sum in the tile bound, and it gives the measured test a threshold relative to the FINAL row sum from
+        // the first chunk on (the running sum after one chunk of eleven is 3.5 bits short of it, which made early chunks of rows that are
+        // nowhere near peaked take the lo half: trained-like weights).
+        float4 ks = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < (L >> 5); i += 64) {
+            const float4 t = ksh[i];
+            ks.x += t.x; ks.y += t.y; ks.z += t.z; ks.w += t.w;
+        }
+        ks.x = wave_sum(ks.x); ks.y = wave_sum(ks.y); ks.z = wave_sum(ks.z); ks.w = wave_sum(ks.w);
+        const float invL = 1.0f / (float)L;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) kbj[j] = row16_min(fmaxf(budget * rqn[j] - knm, 0.f));
+        for (int j = 0; j < 4; ++j) {
+            const float dx = qsv[j].x * ks.x, dy = qsv[j].y * ks.y, dz = qsv[j].z * ks.z, dw = qsv[j].w * ks.w;
+            const float mean = ((dx + dy) + (dz + dw)) * invL, mag = ((fabsf(dx) + fabsf(dy)) + (fabsf(dz) + fabsf(dw))) * invL;
+            jb[j] = log2f((float)L) + mean - 1e-5f * mag - 0.02f;       // slack: the float sums behind kmean and the dot product
+            kbj[j] = row16_min(fmaxf(fmaxf(budget * rqn[j] - knm, (jb[j] - (float)PM) * rqn[j]), 0.f));
+        }
     }
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
                 const bool stale_clears = (skipmask[0] & skipmask[1] & skipmask[2] & skipmask[3] & allmask) == allmask;
                 const bool refresh = !stale_clears && c >= kb_next;         // (kb_next >= 1: the first chunk has no row sum yet)
                 if (refresh) { kb_next = c + kb_gap; kb_gap *= 2; }
-                if (refresh || adapt) {
+                if (refresh || (adapt && !stale_clears)) {       // (a chunk the bound clears whole never looks at thresholds)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // row sum of query li at the start of this chunk: accumulator column 12, row li = lane 16 (li >> 2) + 12, register li & 3
@@ -630,10 +657,12 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
 
                             skipmask[j] = (uint32_t)__ballot(kn_cur < kbj[j]);
                         }
-                        if (adapt) {
+                        if (adapt && !stale_clears) {
                             // measured test: threshold of query li = 2^-PM * that row sum, as an f16 replicated in both halves.  A zero
                             // row sum makes every tile take the lo half; an inf threshold (row sum beyond the f16 range) none.
-                            const _Float16 th = (_Float16)(rs * (1.0f / (float)(1 << PM)));
+                            // (the row sum so far or the lower bound of the final one, whichever is larger; both relative to 2^m)
+                            const float rlb = fmaxf(rs, __builtin_amdgcn_exp2f(jb[j] - mq[j]));
+                            const _Float16 th = (_Float16)(rlb * (1.0f / (float)(1 << PM)));
                             const uint32_t hb = (uint32_t)__builtin_bit_cast(unsigned short, th);
                             thr2[j] = hb | (hb << 16);
                         }
@@ -777,7 +806,7 @@ static int attn_p_mode(int L) {
 
 extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
     const int64_t rows = (int64_t)B * L * H;
-    return rows * 64 + ((rows + 31) / 32) * 4;   // 32 B (K pieces) + 32 B (V image) per key and head, one norm bound per 32 keys
+    return rows * 64 + ((rows + 31) / 32) * 20;  // 32 B (K pieces) + 32 B (V image) per key and head; a key sum (16 B) and a norm bound (4 B) per 32 keys
 }
 
 int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
@@ -801,19 +830,20 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
         uint4* kp = reinterpret_cast<uint4*>(workspace);
         uint4* vp = kp + rows * 2;
         float* kn = kv_image_knorm(workspace, rows);
+        float4* ksm = kv_image_ksum(workspace, rows);
         unsigned long long* redo = reinterpret_cast<unsigned long long*>(redo_events);
         if (!premade) {
-            hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn);
+            hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn, ksm);
             GSDD_CHECK_LAUNCH();
         }
         static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
         const int pmode = attn_p_mode(L);
         float* nolse = nullptr;
-        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
-        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
-        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
-        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
-        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, kn, B, L, H, out, nolse, redo);
+        if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
+        else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
+        else if (pmode == 8) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
+        else if (pmode == 12) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 12>), grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
+        else hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
     } else {
         hipLaunchKernelGGL(d3pm_attention_kernel, grid, dim3(256), 0, st, q, k, v, B, L, H, out);      // (never redoes a chunk)
     }
@@ -834,8 +864,9 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     uint4* kp = reinterpret_cast<uint4*>(workspace);
     uint4* vp = kp + rows * 2;
     float* kn = kv_image_knorm(workspace, rows);
+    float4* ksm = kv_image_ksum(workspace, rows);
     unsigned long long* noredo = nullptr;
-    hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn);
+    hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn, ksm);
     GSDD_CHECK_LAUNCH();
     // The training forward uses the sampler's adaptive lo half at L >= 2048 (the norm-bound form: on flat rows every tile is cleared a
     // priori): its output error <= 2e-5 of the row scale is below what the gradient parity tests resolve (full-size gradient parity and
@@ -843,10 +874,10 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     // everywhere, the round-2 behaviour.
     const char* tp = getenv("GSDD_ATTN_TRAIN_P");
     if (!(tp != nullptr && atoi(tp) == 22) && L >= 2048)
-        hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
+        hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn, ksm,
                            B, L, H, out, lse, noredo);
     else
-        hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn,
+        hipLaunchKernelGGL(d3pm_attention_v4_kernel<384>, dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn, ksm,
                            B, L, H, out, lse, noredo);
     GSDD_CHECK_LAUNCH();
     *done = 1;

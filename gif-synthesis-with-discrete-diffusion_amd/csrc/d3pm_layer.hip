@@ -45,6 +45,7 @@ struct LayerArgs {
     const uint4* wqkv_h2;
     uint4* kimg; uint4* vimg;  // optional: the next block's attention images (k, v go there instead of qkv rows)
     float* knorm;              // with them: per (head, 32-key pair-tile) bound of ||k|| (common.hpp::kv_image_knorm)
+    float4* ksum;              // and the sum of the tile's keys (common.hpp::kv_image_ksum)
     int* range_flag;           // optional (f16 hi + lo kernel): set to 1 when an updated row of x is not finite, i.e. an activation
                                // left the f16 operand range somewhere upstream (inf / NaN reach x through the residual adds)
 };
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_x3p_kernel(const LayerArgs 
                             kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
                         }
                     }
-                    kv_image_store_knorm(o, h, li, grp, a.M, a.knorm);      // M % 32 == 0 here: the group is one whole pair-tile
+                    kv_image_store_knorm(o, h, li, grp, a.M, a.knorm, a.ksum);      // M % 32 == 0 here: the group is one whole pair-tile
                 } else if (full) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -1483,7 +1484,7 @@ __global__ __launch_bounds__(512, 1) void d3pm_layer_h2_kernel(const LayerArgs a
                             kv_image_store_k(vals, (int64_t)hd * a.M + m, a.kimg);
                         }
                     }
-                    kv_image_store_knorm(o, h, li, grp, a.M, a.knorm);      // M % 32 == 0 here: the group is one whole pair-tile
+                    kv_image_store_knorm(o, h, li, grp, a.M, a.knorm, a.ksum);      // M % 32 == 0 here: the group is one whole pair-tile
                 } else if (full) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -1688,11 +1689,13 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     GSDD_CHECK_ARG(variant != 2 || have_x3, "the bf16x3 image kernel needs the gsdd_d3pm_layer_pack images");
     a.kimg = a.vimg = nullptr;
     a.knorm = nullptr;
+    a.ksum = nullptr;
     if (has_qkv && d->kv_img != nullptr) {
         GSDD_CHECK_ARG(variant >= 2 && d->L % 32 == 0, "kv_img needs a packed-weight kernel (fragment images) and L % 32 == 0");
         a.kimg = reinterpret_cast<uint4*>(d->kv_img);
         a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
         a.knorm = kv_image_knorm(d->kv_img, d->M * 16);
+        a.ksum = kv_image_ksum(d->kv_img, d->M * 16);
     }
     GSDD_CHECK_ARG(!qkv_only || has_qkv, "y = NULL (q|k|v stage only) needs qkv");
     if (variant == 3) {

@@ -608,10 +608,15 @@ def test_fused_layer_variants_agree(G, monkeypatch):
         torch.testing.assert_close(a_img, a_ref, atol=1e-6, rtol=0)
         # the per-tile ||k|| bounds written by the layer kernel's epilogue == those of the pre-split pass, and both bound the keys
         ntile = H * M // 32
-        kn_img, kn_ref = ws[H * M * 16:H * M * 16 + ntile], ws_ref[H * M * 16:H * M * 16 + ntile]
+        o_sum, o_norm = H * M * 16, H * M * 16 + 4 * ntile                         # workspace layout: K | V | key sums | tile norms
+        kn_img, kn_ref = ws[o_norm:o_norm + ntile], ws_ref[o_norm:o_norm + ntile]
         torch.testing.assert_close(kn_img, kn_ref, atol=0, rtol=1e-6)
         true_max = k.double().norm(dim=-1).view(ntile, 32).max(dim=1).values
         assert bool((kn_ref.double() >= true_max).all()) and bool((kn_ref.double() <= true_max * (1 + 1e-5) + 1e-30).all())
+        # ... and the per-tile key sums behind the row-sum lower bound: the same summation tree in both producers
+        ks_img, ks_ref = ws[o_sum:o_sum + 4 * ntile].view(ntile, 4), ws_ref[o_sum:o_sum + 4 * ntile].view(ntile, 4)
+        torch.testing.assert_close(ks_img, ks_ref, atol=2e-5, rtol=1e-5)           # (k itself differs in the last bits between the layer variants)
+        torch.testing.assert_close(ks_ref.double(), k.double().view(ntile, 32, 4).sum(dim=1), atol=1e-4, rtol=1e-5)
         monkeypatch.delenv("GSDD_LAYER", raising=False)
 
 

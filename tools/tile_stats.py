@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""How many (16-query x 32-key) tiles of the denoiser's self-attention actually hold a probability above 2^-PM of the row sum, per
+layer, under the reference's init and under the trained-like weights of bench.py -- i.e. what ANY test (bound or measured) could let the
+adaptive attention arithmetic skip.  B = 1, L = 4096, a mid-chain x_t."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gsdd_amd  # noqa: E402
+from gsdd_amd.d3pm_train import D3PMTrainer  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    L, K, H = 4096, 4096, 16
+    torch.manual_seed(0)
+    d = gsdd_amd.DalleMaskImageEmbedding(num_embed=K, spatial_size=[64, 64], embed_dim=64)
+    tr = gsdd_amd.Text2ImageTransformer(dalle=d, n_layer=19, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                        content_spatial_size=[64, 64], condition_dim=512, diffusion_step=100)
+    dm = gsdd_amd.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", auxiliary_loss_weight=5e-4,
+                                       adaptive_auxiliary_loss=True, guidance_scale=2, content_seq_len=L).cuda()
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randint(0, K, (1, L), generator=g).cuda()
+    xt = torch.where(torch.rand((1, L), generator=g).cuda() < 0.5, torch.full_like(x0, K), x0)      # half masked
+    cond = (torch.randn((1, 1, 512), generator=g) * 0.5).cuda()
+    t = torch.tensor([50], device="cuda")
+    for regime in ("init", "trained_like"):
+        if regime == "trained_like":
+            bench.trained_like_weights(dm)
+        trainer = D3PMTrainer(dm, lr=1e-4)
+        sv = trainer._forward(xt, cond, t)
+        for li in (0, 1, 5, 10, 18):
+            qkv = sv["layers"][li]["qkv"]                       # [3H][M][4]
+            q, k = qkv[0:H].double(), qkv[H:2 * H].double()
+            fr = {8: 0.0, 6: 0.0, 10: 0.0}
+            nq = 512                                           # a sample of query rows per head
+            s = (q[:, :nq] @ k.transpose(1, 2)) * 0.5 * 1.4426950408889634          # log2 domain, [H][nq][L]
+            lse = torch.logsumexp(s * 0.6931471805599453, dim=-1, keepdim=True) * 1.4426950408889634
+            rel = s - lse                                       # log2(p / rowsum)
+            tile = rel.reshape(H, nq // 16, 16, L // 32, 32).amax(dim=(2, 4))        # max over the tile
+            for pm in fr:
+                fr[pm] = float((tile > -pm).double().mean())
+            qn, kn = q.norm(dim=-1), k.norm(dim=-1)
+            print(f"{regime:12s} layer {li:2d}: |q| mean {float(qn.mean()):.2f} max {float(qn.max()):.2f}  |k| mean {float(kn.mean()):.2f} max "
+                  f"{float(kn.max()):.2f}  score std {float((s * 0.693).std()):.2f}  tiles with p > 2^-6 / 2^-8 / 2^-10 of the row sum: "
+                  f"{fr[6]:.3f} / {fr[8]:.3f} / {fr[10]:.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
