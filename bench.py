@@ -124,6 +124,7 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
     roof = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src, "ms_per_launch": round(ms, 4),
             "launches_timed": n, "flops_per_launch": flops,
+            "ms_by_block": [round(sum(e0.elapsed_ms(e1) for e0, e1 in events["attention"][i::n // reps]) / reps, 3) for i in range(n // reps)],
             "timed_as": f"one full batch of {B2} rows on one stream, after the timed region"}
 
     fam = {}
@@ -367,6 +368,7 @@ def main():
                 try:
                     roof_t, _ = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid, reps=1)
                     extra["trained_like_attention_ms_per_launch"] = roof_t["ms_per_launch"]
+                    extra["trained_like_attention_ms_by_block"] = roof_t["ms_by_block"]       # blocks 1..18 (block 0 is a half batch)
                 except Exception:                                # noqa: BLE001
                     pass
                 line["extra"] = extra
