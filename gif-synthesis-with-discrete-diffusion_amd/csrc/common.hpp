@@ -182,18 +182,25 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-// sum over the 32 lanes of a half (same exchange pattern as the maxima: every lane ends with the same bits)
+// lane 15 of DPP rows 0 / 2 broadcast to the lanes of rows 1 / 3 (row_bcast:15 with row_mask 0b1010; the other rows read 0): the step
+// that joins the two rows of a 32-lane half without leaving the vector ALU (a __shfl_xor goes through the LDS permute path)
+__device__ __forceinline__ float dpp_prev_row_lane15(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+}
+// sum over the 32 lanes of a half; valid in the UPPER 16 lanes of the half (lanes 16..31 and 48..63).  A fixed tree: the same bits for
+// the same inputs in every producer and every run.
 __device__ __forceinline__ float half32_sum(float v) {
     v = dpp_add<0xB1>(v);
     v = dpp_add<0x4E>(v);
     v = dpp_add<0x141>(v);
     v = dpp_add<0x140>(v);
-    return v + __shfl_xor(v, 16);
+    return v + dpp_prev_row_lane15(v);
 }
-// ||k|| bound of one pair-tile from per-lane squared norms: lanes of a 32-lane half hold the 32 keys; lane 0 of the half gets it
+// ||k|| bound of one pair-tile from per-lane squared norms: lanes of a 32-lane half hold the 32 keys; valid in the upper 16 lanes of
+// the half (squared norms are non-negative, so the 0 the lower rows read in the joining step is harmless)
 __device__ __forceinline__ float half32_norm_bound(float n2) {
     float v = row16_max(n2);
-    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, dpp_prev_row_lane15(v));
     return sqrtf(v) * 1.000001f + 1e-30f;
 }
 // fused layer kernels: lane (li = row of the 32-row group, h) holds k of heads 8 (q >> 2) + 2 (q & 3) + h in o[q]
@@ -205,10 +212,12 @@ __device__ __forceinline__ void kv_image_store_knorm(const float4 (&o)[8], int h
         const float nb = half32_norm_bound(n2);
         const float4 sk = make_float4(half32_sum(o[q].x), half32_sum(o[q].y), half32_sum(o[q].z), half32_sum(o[q].w));
         const int hd = 8 * (q >> 2) + 2 * (q & 3) + h;
-        if (li == 0) {
+        if (li == 16) {                           // (the reductions are valid in the upper 16 lanes of each half)
             knorm[(int64_t)hd * (M >> 5) + grp] = nb;
             ksum[(int64_t)hd * (M >> 5) + grp] = sk;
         }
+        // one head at a time: interleaved, the eight heads' reduction chains keep 40 temporaries alive in kernels that already spill
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void d3pm_attn_prep_kernel(const float* __rest
     kv_image_store_v(vs, row, vp);
     const float nb = half32_norm_bound((rk.x * rk.x + rk.y * rk.y) + (rk.z * rk.z + rk.w * rk.w));
     const float4 sk = make_float4(half32_sum(rk.x), half32_sum(rk.y), half32_sum(rk.z), half32_sum(rk.w));
-    if ((threadIdx.x & 31) == 0) {
+    if ((threadIdx.x & 31) == 16) {                                   // (the reductions are valid in the upper 16 lanes of each half)
         knorm[row >> 5] = nb;
         ksum[row >> 5] = sk;
     }
@@ -489,6 +489,18 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
     const int li = lane & 15, lg = lane >> 4;
     const int q0 = qblk * 256 + wave * 64;
 
+    // PM >= 2: the tile norms and key sums of this (b, h), requested first so that their latency hides behind the q splits, the first
+    // chunk's staging and the first 64 keys' score maximum (they are consumed just before the chunk loop)
+    float knm = 0.f;
+    float4 ks = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PM >= 2) {
+        for (int i = lane; i < (L >> 5); i += 64) {
+            knm = fmaxf(knm, knh[i]);
+            const float4 t = ksh[i];
+            ks.x += t.x; ks.y += t.y; ks.z += t.z; ks.w += t.w;
+        }
+    }
+
     if (tid < 16) sm.ones[tid] = (tid == 0 || tid == 1) ? make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
 
     const float qscale = 0.5f * 1.4426950408889634f;
@@ -583,8 +595,6 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         //     ||q'|| knorm[u] - m < log2(L) - PM - ||q'|| KNmax - m   <=>   knorm[u] < (log2(L) - PM - slack) / ||q'|| - KNmax.
         // With near-flat rows (||q'|| ||k|| << log2(L) - PM = 4 at L = 4096) this clears every tile of every chunk, the first included,
         // and the running-sum form below never has to be computed.
-        float knm = 0.f;
-        for (int i = lane; i < (L >> 5); i += 64) knm = fmaxf(knm, knh[i]);
         knm = wave_max(knm) * 1.0001f;
         const float budget = log2f((float)L) - (float)PM - 0.02f;
         // Sharper, and per query: Jensen -- log2 sum_j 2^(q'.k_j) >= log2(L) + q'.kmean, kmean from the per-tile key sums the K image's
@@ -593,11 +603,6 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
         // It replaces the a priori row sum in the tile bound, and it gives the measured test a threshold relative to the FINAL row sum from
         // the first chunk on (the running sum after one chunk of eleven is 3.5 bits short of it, which made early chunks of rows that are
         // nowhere near peaked take the lo half: trained-like weights).
-        float4 ks = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = lane; i < (L >> 5); i += 64) {
-            const float4 t = ksh[i];
-            ks.x += t.x; ks.y += t.y; ks.z += t.z; ks.w += t.w;
-        }
         ks.x = wave_sum(ks.x); ks.y = wave_sum(ks.y); ks.z = wave_sum(ks.z); ks.w = wave_sum(ks.w);
         const float invL = 1.0f / (float)L;
 #pragma unroll
