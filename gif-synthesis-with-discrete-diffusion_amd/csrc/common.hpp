@@ -216,8 +216,6 @@ __device__ __forceinline__ void kv_image_store_knorm(const float4 (&o)[8], int h
             knorm[(int64_t)hd * (M >> 5) + grp] = nb;
             ksum[(int64_t)hd * (M >> 5) + grp] = sk;
         }
-        // one head at a time: interleaved, the eight heads' reduction chains keep 40 temporaries alive in kernels that already spill
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
