@@ -174,11 +174,13 @@ int gsdd_small_linear(const float* x, int R, int Cin, const float* w, const floa
  * softmax(q k^T / sqrt(4)) v, scores never leave registers.
  * Replaces FullAttention.forward: transformer_utils.py:46-62 (head-mean att is dropped: unused). */
 /* workspace: gsdd_d3pm_attention_workspace_bytes(B,L,H) bytes of scratch for the matrix-pipe kernel: the pre-split K image
- * (32 B per key and head), the V image (32 B) and one f32 per (head, 32-key pair-tile) bounding the tile's largest ||k||, which
- * lets the kernel prove from ||q|| ||k|| alone that a tile holds no probability above 2^-8 of its row sum (then only the f16 hi
- * half of P is used for it).  NULL selects the workspace-free kernel (exact-f32 P.V on v_mfma_f32_4x4x1). */
+ * (32 B per key and head), the V image (32 B) and, per (head, 32-key pair-tile), the sum of the tile's keys (float4) and one f32
+ * bounding the tile's largest ||k||.  The norms let the kernel prove from ||q|| ||k|| alone that a tile holds no probability above
+ * 2^-8 of its row sum (then only the f16 hi half of P is used for it); the sums give it the mean key, hence a lower bound of every
+ * final row sum before a key has been seen.  NULL selects the workspace-free kernel (exact-f32 P.V on
+ * v_mfma_f32_4x4x1). */
 int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H);
-/* k = v = NULL: the workspace already holds the images and norms (written by gsdd_d3pm_layer through kv_img).
+/* k = v = NULL: the workspace already holds the images, key sums and norms (written by gsdd_d3pm_layer through kv_img).
  * redo_events: optional device counter (caller-owned, caller-zeroed) to which the kernel adds one per (wave, chunk) it had to
  * redo with a larger exponent offset after an f16 overflow -- the kernel's only other data-dependent cost, 0 for near-uniform
  * attention rows.  The library keeps no counter of its own (no hidden global state). */
