@@ -350,10 +350,11 @@ def test_d3pm_attention(G, B, L, spike, use_ws):
     assert err < 2e-5, err
 
 
-@pytest.mark.parametrize("case", ["flat", "hot_tile", "hot_query", "growing_norms", "zero_q"])
+@pytest.mark.parametrize("case", ["flat", "hot_tile", "hot_query", "growing_norms", "zero_q", "mean_shift", "two_clusters", "unit_scale"])
 def test_attention_norm_bound(G, case, monkeypatch):
-    """The adaptive mode's bound (kernel note in d3pm_attention.hip): tiles whose ||q|| ||k|| bound keeps every probability below 2^-8
-    of the row sum take the f16 hi half only, decided without looking at the scores.  Near-flat rows (the reference init) clear every
+    """The adaptive mode's bounds (kernel note in d3pm_attention.hip): tiles whose ||q|| ||k|| bound keeps every probability below 2^-8
+    of the row sum -- the row sum so far, or the lower bound of the final one from the mean key (Jensen) -- take the f16 hi half only,
+    decided without looking at the scores; where the bound does not decide, the measured test compares with the same row sums.  Near-flat rows (the reference init) clear every
     chunk after the first; a tile of large keys, or a query of large norm inside a sub-tile, must not be cleared: the result has to
     stay within the kernel's 2e-5 of fp64 and within the adaptive mode's budget of the all-hi+lo result."""
     B, L, H = 1, 4096, 16
@@ -369,6 +370,14 @@ def test_attention_norm_bound(G, case, monkeypatch):
         k = k * torch.linspace(0.5, 12.0, L).view(1, 1, L, 1)
     elif case == "zero_q":
         q[:, :, :64] = 0.0
+    elif case == "mean_shift":      # keys with a large common component: q . kmean is +-6 bits, the row-sum lower bound (Jensen) moves
+        k = k + torch.tensor([3.0, -2.0, 1.0, 0.5])               # every query's threshold, up for aligned queries and down for opposed ones
+        q = q * 4.0
+    elif case == "two_clusters":    # half of the keys far from the other half: log-mean-exp is far above the mean score, the bound is
+        k[:, :, ::2] += torch.tensor([4.0, 0.0, 0.0, 0.0])        # loose (never wrong) and the measured test has to do the work
+        q = q * 6.0
+    elif case == "unit_scale":      # structureless unit-scale q, k (trained-like spread): a quarter of the tiles hold a probability
+        q, k = q / 0.15, k / 0.15                                 # above the threshold
     want = attention_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, H * 4)
     hm = lambda z: dev(z.permute(1, 0, 2, 3).reshape(H, B * L, 4).contiguous())
     outs = {}
