@@ -186,6 +186,39 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
     }
 }
 
+// The fused kernel's pre-split: only the two score-row images.  A block takes 16 consecutive rows m of all 16 heads: dO and O are read
+// as the row-major [m][h][4] arrays they are (16 threads cover one row's 256 bytes; the per-head kernel above reads 16 of every 256
+// bytes per wave and fetched 2.9x the bytes), handed over through LDS, and the images are written head-major, 16 rows = 768
+// contiguous bytes per head.  H == 16, M % 16 == 0.
+__global__ __launch_bounds__(256) void attn_bwd_prep_fused_kernel(const float* __restrict__ q, const float* __restrict__ o,
+                                                                  const float* __restrict__ dO, const float* __restrict__ lse, int64_t M,
+                                                                  BwdImages im) {
+    __shared__ float4 gs_s[16][17];
+    __shared__ float dl_s[16][17];
+    const int t = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    {
+        const int ml = t >> 4, h = t & 15;
+        const float4 rg = *reinterpret_cast<const float4*>(dO + (m0 + ml) * 64 + h * 4);
+        const float4 ro = *reinterpret_cast<const float4*>(o + (m0 + ml) * 64 + h * 4);
+        gs_s[h][ml] = rg;
+        dl_s[h][ml] = (rg.x * ro.x + rg.y * ro.y) + (rg.z * ro.z + rg.w * ro.w);
+    }
+    __syncthreads();
+    const int h = t >> 4, ml = t & 15;
+    const int64_t row = (int64_t)h * M + m0 + ml;
+    const float4 rq = *reinterpret_cast<const float4*>(q + row * 4);
+    const float4 rg = gs_s[h][ml];
+    const float delta = dl_s[h][ml];
+    const float c = 0.5f * 1.4426950408889634f;
+    const float qs[4] = {rq.x * c, rq.y * c, rq.z * c, rq.w * c}, gs[4] = {rg.x, rg.y, rg.z, rg.w};
+    uint4 pa, pb;
+    bw_row_pieces(qs, pa, pb);
+    im.qp[row * 3 + 0] = pa; im.qp[row * 3 + 1] = pb; im.qp[row * 3 + 2] = bw_slot_frag(-lse[row]);
+    bw_row_pieces(gs, pa, pb);
+    im.gp[row * 3 + 0] = pa; im.gp[row * 3 + 1] = pb; im.gp[row * 3 + 2] = bw_slot_frag(-delta);
+}
+
 __device__ __forceinline__ unsigned bw_xcd_remap(unsigned wg, unsigned nwg) {
     const unsigned q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -748,8 +781,11 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     im.gv = w;
     hipStream_t st = (hipStream_t)stream;
     const bool split_kernels = getenv("GSDD_ATTN_BWD_SPLIT") != nullptr;            // A/B switch (read per call): dQ kernel + dK/dV kernel
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, q, k, v, o, dO, lse, M, H, im,
-                       split_kernels);
+    if (!split_kernels && H == 16 && M % 16 == 0)
+        hipLaunchKernelGGL(attn_bwd_prep_fused_kernel, dim3((unsigned)(M / 16)), dim3(256), 0, st, q, o, dO, lse, M, im);
+    else
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, q, k, v, o, dO, lse, M, H, im,
+                           split_kernels);
     GSDD_CHECK_LAUNCH();
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
     if (!split_kernels) {
