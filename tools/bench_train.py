@@ -27,18 +27,22 @@ def main():
     losses = []
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     times = []
+    hosts = []
     for i in range(steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = trainer.step(tok, cond)
+        host = time.perf_counter() - t0                     # python has enqueued the whole step
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        hosts.append(host * 1e3)
         losses.append(float(loss[0]))
         times.append(dt * 1e3)
         print(f"step {i}: loss {losses[-1]:.4f}  {dt * 1e3:.1f} ms  ({B / dt:.1f} samples/s)  mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     if steps > 4:
         tail = sorted(times[2:])
-        print(f"median of steps 2..{steps - 1}: {tail[len(tail) // 2]:.2f} ms  (min {tail[0]:.2f})")
+        print(f"median of steps 2..{steps - 1}: {tail[len(tail) // 2]:.2f} ms  (min {tail[0]:.2f}); host enqueue time median "
+              f"{sorted(hosts[2:])[len(hosts[2:]) // 2]:.2f} ms")
 
 
 if __name__ == "__main__":
