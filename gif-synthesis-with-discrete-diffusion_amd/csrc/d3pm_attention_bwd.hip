@@ -8,8 +8,11 @@
 //     dp - delta directly;
 //   * P and dS (f32 in registers) are split hi + lo in bf16 (16 significant bits) and multiplied with the 3-way bf16 splits of
 //     dO / K / Q on the matrix pipe (products exact in the f32 accumulator), like P.V in the forward.
-// Two kernels: dQ (a wave owns 64 queries, keys stream through LDS) and dK/dV (a wave owns 64 keys, queries stream).
-// All operand images are pre-split once per call by attn_bwd_prep_kernel (256 B per (row, head)).
+// The shipped path is ONE fused kernel (a wave owns 64 keys, queries stream through LDS, dS crosses an LDS transpose for dQ; section
+// "fused backward" below) fed by attn_bwd_prep_fused_kernel, which pre-splits only the two score-row images of Q and dO (96 B per
+// (row, head)): the accumulate-side fragments are transposed LDS reads of those images, the key-side images are built by the waves that
+// own the keys.  GSDD_ATTN_BWD_SPLIT selects the older pair -- dQ (a wave owns 64 queries, keys stream) and dK/dV (a wave owns 64 keys,
+// queries stream) -- with all seven operand images pre-split by attn_bwd_prep_kernel (256 B per (row, head)).
 //
 // Reference semantics: autograd of FullAttention.forward (transformer_utils.py:46-62).
 #include <stdlib.h>
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(const float* 
 //     stores and the previous chunk's slab flush run inside the compute phase instead of between two barriers (measured: the two
 //     barriers with the flush and the staging stores between them cost 15 % of the kernel).
 // Per 512 scores: 4 score MFMAs, 8 v_exp, 2 hi/lo splits, 6 accumulate MFMAs (dV, dK, dQ) -- against 8 + 16 + 3 + 6 for the pair.
+// (Chunk = FQ queries, 96 by default.)
 // FQC = queries per LDS chunk (template parameter FQ); the slab column stride in floats is FQC + 16 (the 4-byte stores of lane
 // groups 0 / 1 -- columns 0 / 1 -- land on banks 0..15 / 16..31)
 template <int FQC>
@@ -757,8 +761,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __
 using namespace gsdd;
 
 extern "C" int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H) {
-    // 16 uint4 per (row, head): kp 2, vk 2, kv 2, qp 3, gp 3, qv 2, gv 2; then the fused kernel's partial dQ: one float4 per
-    // (256-key block, row, head)
+    // 16 uint4 per (row, head): kp 2, vk 2, kv 2, qp 3, gp 3, qv 2, gv 2 (the fused kernel uses qp and gp only; the layout is the
+    // two-kernel variant's); then the fused kernel's partial dQ: one float4 per (256-key block, row, head)
     return (int64_t)B * L * H * 16 * 16 + (int64_t)((L + 255) / 256) * B * L * H * 16;
 }
 
