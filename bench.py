@@ -341,8 +341,11 @@ def main():
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra:
             # regimes the dominant kernel could be sensitive to, outside the timed headline (same process, one warm + one timed
-            # pass each): the reference-faithful zero conditioning, one lane instead of two, and weights of a trained-like
-            # magnitude (peaky softmax rows); redo_chunks = overflow-redo events of the attention kernel per timed pass
+            # pass each): the reference-faithful zero conditioning (DiscreteDiffusion.forward zeroes BOTH embeddings,
+            # discrete_diffusion.py:25, :49: the two guidance copies are then the same computation and sample() runs one of them --
+            # zero_cond_guidance_copies says how many ran; the headline's condition differs from the unconditional one and runs
+            # two), one lane instead of two, and weights of a trained-like magnitude (peaky softmax rows); redo_chunks =
+            # overflow-redo events of the attention kernel per timed pass
             try:
                 def timed(cond_):
                     nonlocal cond
@@ -359,6 +362,7 @@ def main():
                 if families is not None:
                     extra["roofline_families"] = families
                 extra["zero_cond"], extra["redo_chunks_zero_cond"] = timed(torch.zeros_like(cond))
+                extra["zero_cond_guidance_copies"] = 1 if getattr(dm, "_last_cfg_dedupe", False) else 2
                 other = 1 if lanes_used > 1 else 2
                 dm.sample_lanes = other                        # same tokens either way: the noise key is the global row
                 extra["one_lane" if other == 1 else "two_lanes"], _ = timed(cond)

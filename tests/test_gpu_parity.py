@@ -292,6 +292,28 @@ def test_full_reverse_loop_tokens_bit_exact(G, golden):
     assert np.array_equal(out_g["content_token"].cpu().numpy(), a["loop_tokens"])
 
 
+def test_identical_guidance_copies_run_once(G, golden, monkeypatch):
+    """The reference's shipped inference path zeroes both the conditional and the unconditional embedding (discrete_diffusion.py:25, :49):
+    the two guidance copies are then the same computation, and sample() runs one of them, feeding its logits to both sides of the guided
+    mix.  Tokens must equal the two-copy run's (GSDD_CFG_DEDUPE=0) over the whole captured 100-step loop; different embeddings must
+    keep both copies."""
+    sd, a, cfg = golden("d3pm_L64")
+    dm = build_d3pm(G, sd, cfg)
+    B = cfg["B"]
+    zero = torch.zeros_like(dev(a["step_cond"]))
+    toks = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GSDD_CFG_DEDUPE", mode)
+        dm.set_noise(cfg["noise_seed"])
+        toks[mode] = dm.sample(["a"] * B, None, zero, zero.clone(), filter_ratio=0, use_graph=True)["content_token"].cpu().numpy()
+        assert dm._last_cfg_dedupe == (mode == "1")
+    assert np.array_equal(toks["1"], toks["0"])
+    monkeypatch.setenv("GSDD_CFG_DEDUPE", "1")
+    dm.set_noise(cfg["noise_seed"])
+    out = dm.sample(["a"] * B, None, dev(a["step_cond"]), zero, filter_ratio=0, use_graph=True)
+    assert not dm._last_cfg_dedupe and np.array_equal(out["content_token"].cpu().numpy(), a["loop_tokens"])
+
+
 def test_long_sequence_loop_tokens_bit_exact_vs_reference(G, golden):
     """The reference's own 100-step reverse loop at L = 2048 (`d3pm_L2048`: one clip, two layers, K = 32, trained-like weights),
     where the attention kernel runs its default adaptive P arithmetic (f16 hi, lo where the norm bound / the measured test ask for
