@@ -6,6 +6,7 @@ src/models/networks/discrete_diffusion.py.  The nn.Module tree only owns paramet
 reference's names; the sampling loop runs as one captured hipGraph per reverse
 step, replayed diffusion_step times with the timestep and the Philox stream id living in device memory.
 """
+import collections.abc
 import contextlib
 import os
 
@@ -653,6 +654,48 @@ def _instantiate(cfg):
     return instantiate(cfg)
 
 
+class Deferred:
+    """A value of LazyOutputs that is computed when somebody asks for it."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
+class LazyOutputs(collections.abc.MutableMapping):
+    """The generator's output dict with its two pure, unconditionally computed by-products deferred: `pred_data` (training: the decode
+    of the single-step prediction) / `pred_single_step` (inference) and `test` (the decode of the input's own codes) are full VQ-VAE
+    decodes -- 2 x 30 ms at bs 16 beside a 57 ms denoiser step -- that the reference's stage-2 training step computes and never reads
+    (its loss is `outputs['losses']`: metrics/loss_func.py:10-14, multistage_text_motion_model.py:170-190).  They are deterministic
+    functions of tokens and frozen weights, so computing them on first access gives every reader the same tensors; readers that copy the
+    mapping (`dict.update`, `dict(...)`) trigger them, as do `items()` / `values()`.  `pending()` lists what has not been computed."""
+
+    def __init__(self, **items):
+        self._d = dict(items)
+
+    def __getitem__(self, k):
+        v = self._d[k]
+        if isinstance(v, Deferred):
+            with torch.no_grad():
+                v = v.fn()
+            self._d[k] = v
+        return v
+
+    def __setitem__(self, k, v):
+        self._d[k] = v
+
+    def __delitem__(self, k):
+        del self._d[k]
+
+    def __iter__(self):
+        return iter(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    def pending(self):
+        return sorted(k for k, v in self._d.items() if isinstance(v, Deferred))
+
+
 class DiscreteDiffusion(nn.Module):
     """Drop-in for src/models/networks/discrete_diffusion.py:8-83 (generator glue).  `textencoder` and
     `diffusion_model` may be already-built modules or (with hydra present) configs to instantiate.
@@ -694,18 +737,26 @@ class DiscreteDiffusion(nn.Module):
         diffusion_out = self.diffusion_model({"condition_embed_token": text_emb, "content_token": quant_flat},
                                              return_loss=True, return_logits=False)   # (`logits` = exp(log_model_prob), a (B, K+1, L)
         # tensor the reference computes here and never reads (discrete_diffusion.py:38-41, :66-81): not asked for, so the loss and its gradient take the one-pass kernel)
+        # arg-max over K+1 classes can only return [MASK] when every code row sits at the -70 clamp; the reference would
+        # then fail inside F.embedding, we decode code K-1 instead
+        pred_tokens = diffusion_out["pred_data"].view(quant.shape).clamp(max=autoencoder.n_codes - 1)
+        # the two decodes nobody may ever read (LazyOutputs): deferred while the VQ-VAE is frozen in eval mode (a train-mode decode
+        # would update BatchNorm statistics: then it happens here, as in the reference); GSDD_EAGER_OUTPUTS=1 computes them here too
+        lazy = (not autoencoder.training) and os.environ.get("GSDD_EAGER_OUTPUTS") is None
+        single_step_out = Deferred(lambda: autoencoder.decode(pred_tokens))
+        test = Deferred(lambda: autoencoder.decode(quant))
         with torch.no_grad():
-            # arg-max over K+1 classes can only return [MASK] when every code row sits at the -70 clamp; the reference would
-            # then fail inside F.embedding, we decode code K-1 instead
-            single_step_out = autoencoder.decode(diffusion_out["pred_data"].view(quant.shape).clamp(max=autoencoder.n_codes - 1))
-            if do_inference:
+            if do_inference:                # (the sampler draws from the noise stream: always at this point of the call)
                 inference_out = self.sample_videos(batch["text"], autoencoder, latent_shape=tuple(quant.shape[1:]),
                                                    text_emb=text_emb)
-            test = autoencoder.decode(quant)
         if do_inference:
-            return {"pred_data": inference_out, "pred_single_step": single_step_out, "gt_data": x,
-                    "losses": diffusion_out["loss"], "test": test}
-        return {"pred_data": single_step_out, "gt_data": x, "losses": diffusion_out["loss"], "test": test}
+            out = LazyOutputs(pred_data=inference_out, pred_single_step=single_step_out, gt_data=x, losses=diffusion_out["loss"], test=test)
+        else:
+            out = LazyOutputs(pred_data=single_step_out, gt_data=x, losses=diffusion_out["loss"], test=test)
+        if not lazy:
+            for k in list(out):
+                out[k]
+        return out
 
     @torch.no_grad()
     def sample_videos(self, texts, autoencoder, latent_shape=None, text_emb=None):

@@ -66,12 +66,14 @@ class MultistageTextMotionModel(BaseModel):
                 load_reference_checkpoint(getattr(self, key), path)
 
     def generator_step(self, batch):                                    # :149-157
-        outputs = dict(self.generator(batch, self.autoencoder, self.length_estimator))
+        # (the generator's mapping is kept as it is, not copied into a dict: its two decoded by-products are computed only if read --
+        # gsdd_amd.d3pm.LazyOutputs; the stage-2 loss reads `losses` alone)
+        outputs = self.generator(batch, self.autoencoder, self.length_estimator)
         outputs["length"] = batch["length"]
         return outputs
 
     def sample_generator_step(self, batch):                             # :160-168
-        outputs = dict(self.generator(batch, self.autoencoder, self.length_estimator, do_inference=True))
+        outputs = self.generator(batch, self.autoencoder, self.length_estimator, do_inference=True)
         outputs["length"] = batch["length"]
         return outputs
 

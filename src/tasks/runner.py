@@ -202,7 +202,7 @@ def evaluate(cfg):
     datamodule, model, trainer = build(cfg)
     t0 = time.perf_counter()
     outs = trainer.test(model, datamodule, ckpt_path=cfg.get("ckpt_path"))
-    n = sum(o["pred_data"].shape[0] for o in outs if isinstance(o, dict) and torch.is_tensor(o.get("pred_data")))
+    n = sum(o["pred_data"].shape[0] for o in outs if hasattr(o, "get") and torch.is_tensor(o.get("pred_data")))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"test: {len(outs)} batches ({n} sampled clips) in {dt:.2f} s", trainer.callback_metrics)

@@ -86,6 +86,36 @@ def test_glue_forward_matches_reference_output_dict(G, golden, tag):
     assert out2["losses"].item() == out["losses"].item()
 
 
+def test_generator_defers_unread_decodes(G, golden, monkeypatch):
+    """The glue's two decoded by-products are computed when read (LazyOutputs): a training-shaped call that reads `losses` only leaves
+    them pending; reading them gives the tensors of an eager call (GSDD_EAGER_OUTPUTS=1); copying the mapping computes them."""
+    gen, vq, batch, a, cfg, cfgd = build(G, golden)
+    dm = gen.diffusion_model.eval()
+    pin_time(dm, a, cfgd["T"])
+    outs = {}
+    for mode in ("lazy", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("GSDD_EAGER_OUTPUTS", "1")
+        dm.set_noise(cfg["noise_seed"], stream=int(cfg["stream"]))
+        dm.Lt_history.zero_(); dm.Lt_count.zero_()
+        with torch.no_grad():
+            out = gen(batch, vq, None)
+        assert out.pending() == (["pred_data", "test"] if mode == "lazy" else [])
+        _ = out["losses"]
+        assert out.pending() == (["pred_data", "test"] if mode == "lazy" else [])
+        outs[mode] = out
+    copied = dict(outs["lazy"])
+    assert outs["lazy"].pending() == [] and set(copied) == {"pred_data", "gt_data", "losses", "test"}
+    for key in ("pred_data", "test"):
+        assert torch.equal(copied[key], outs["eager"][key])
+    # a VQ-VAE in train mode decodes at once (its BatchNorm statistics move with every decode, as in the reference)
+    monkeypatch.delenv("GSDD_EAGER_OUTPUTS")
+    vq.train()
+    with torch.no_grad():
+        assert gen(batch, vq, None).pending() == []
+    vq.eval()
+
+
 def test_glue_loss_backward_fills_transformer_grads(G, golden):
     """generator(batch, autoencoder)['losses'].backward() -- the call path of multistage_text_motion_model.py:170-197."""
     from gsdd_amd.d3pm_train import D3PMTrainer
