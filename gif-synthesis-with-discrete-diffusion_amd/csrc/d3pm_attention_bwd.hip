@@ -529,14 +529,6 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint2* p) {
     const bw_v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bw_v4s*)(p));
     return __builtin_bit_cast(uint2, r);
 }
-// x[lane] + x[lane + 4] + x[lane + 8] within a 16-lane row (DPP row_shl; lanes past the row read 0): the sum of the three K pieces
-__device__ __forceinline__ float bw_piece_sum(float x) {
-    const int xi = __float_as_int(x);
-    const float a = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x104, 0xf, 0xf, true));
-    const float b = __int_as_float(__builtin_amdgcn_update_dpp(0, xi, 0x108, 0xf, 0xf, true));
-    return (x + a) + b;
-}
-
 template <int DBG, int NW = 4, int FQ = 128>   // DBG 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing only)
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float* __restrict__ k, const float* __restrict__ v, BwdImages im,
                                                                     int B, int L, int H, float* __restrict__ dqkv,
