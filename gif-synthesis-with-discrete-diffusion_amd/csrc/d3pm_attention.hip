@@ -697,7 +697,9 @@ __global__ __launch_bounds__(256) void d3pm_attention_v4_kernel(const float* __r
             if (!__any(bad)) {
                 if (PM >= 2 && !cleared) {                               // (a cleared chunk says nothing about the measured test)
                     if (adapt) {
-                        if (2 * skipped < 4 * npairs) { adapt = false; probe = backoff; backoff *= 2; }
+                        // (a tile that fails the test pays for the test, a taken branch and the lo half in a loop that cannot overlap
+                        // them: measured, a chunk with 30 % such tiles costs 1.13 plain hi + lo chunks; the break-even is between 15 and 30 %)
+                        if (10 * skipped < 7 * 4 * npairs) { adapt = false; probe = backoff; backoff *= 2; }
                     } else if (--probe <= 0) {
                         adapt = true;
                     }
