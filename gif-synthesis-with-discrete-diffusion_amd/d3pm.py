@@ -692,6 +692,9 @@ class LazyOutputs(collections.abc.MutableMapping):
     def __len__(self):
         return len(self._d)
 
+    def __contains__(self, k):                  # (the Mapping default would go through __getitem__ and compute the value)
+        return k in self._d
+
     def pending(self):
         return sorted(k for k, v in self._d.items() if isinstance(v, Deferred))
 

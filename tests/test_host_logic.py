@@ -427,3 +427,45 @@ def test_clip_text_provider_runs_a_supplied_local_tower(tmp_path):
         CLIPTextEmbedding(clip_dim=512, weights=str(tmp_path))
     h = CLIPTextEmbedding(clip_dim=512)(["a", "b", "a"])
     assert tuple(h.shape) == (3, 512) and torch.equal(h[0], h[2]) and not torch.equal(h[0], h[1])
+
+
+def test_lazy_outputs_compute_on_first_access_only():
+    """gsdd_amd.d3pm.LazyOutputs (the generator glue's output mapping): deferred values are computed once, when read; `losses`-only
+    readers leave them pending; copying the mapping computes them; the mapping takes new keys like the dict the reference returns."""
+    from gsdd_amd.d3pm import Deferred, LazyOutputs
+    calls = []
+
+    def make(tag):
+        def fn():
+            calls.append(tag)
+            assert not torch.is_grad_enabled()
+            return torch.full((2,), float(len(calls)))
+        return Deferred(fn)
+
+    out = LazyOutputs(pred_data=make("pred"), gt_data=torch.zeros(2), losses=torch.ones(()), test=make("test"))
+    assert set(out) == {"pred_data", "gt_data", "losses", "test"} and len(out) == 4 and "test" in out
+    assert out.pending() == ["pred_data", "test"] and calls == []
+    assert float(out["losses"]) == 1.0 and out.get("missing") is None and calls == []
+    first = out["test"]
+    assert calls == ["test"] and out["test"] is first and out.pending() == ["pred_data"]
+    out["length"] = [16, 16]
+    copied = dict(out)
+    assert calls == ["test", "pred"] and out.pending() == [] and copied["length"] == [16, 16] and copied["pred_data"] is out["pred_data"]
+    target = {}
+    target.update(LazyOutputs(a=make("a"), b=3))
+    assert torch.is_tensor(target["a"]) and target["b"] == 3 and calls[-1] == "a"
+
+
+def test_bench_reads_attention_traffic_of_its_own_grid_from_the_committed_profile():
+    """bench.py's `roofline.traffic` is read from profiles/r*_pmc_traffic.csv for the kernel AND the bench shape's grid (8192
+    workgroups at 2B = 32 rows, L = 4096, 16 heads); the training forward's launches of the same kernel (grid 4096) must not be mixed in."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full, src = bench.profile_traffic("d3pm_attention_v4_kernel<384, 8>", 8192)
+    half, _ = bench.profile_traffic("d3pm_attention_v4_kernel<384, 8>", 4096)
+    assert src is not None and src.endswith("_pmc_traffic.csv")
+    assert 1.9e8 < full < 2.2e8 and 0.9e8 < half < 1.2e8
+    assert bench.profile_traffic("no_such_kernel", 1) == (None, None)
