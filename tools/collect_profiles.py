@@ -23,6 +23,8 @@ copy("bench.summary.csv", "bench_kernel_stats.csv")
 copy("bench.bygrid.csv", "bench_kernel_stats_by_grid.csv")
 copy("nearest.bygrid.csv", "nearest_code_kernel_stats.csv")
 copy("train.summary.csv", "d3pm_train_kernel_stats.csv")
+if os.path.exists(os.path.join(P, "vqtrain.summary.csv")):
+    copy("vqtrain.summary.csv", "vqvae_train_kernel_stats.csv")
 copy("traffic.csv", "pmc_traffic.csv", (
     "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/bench_kernels.py attn step attnbwd nearest   (tools/profile_round.sh; tools/make_traffic_csv.py)",
     "one row per (kernel; grid size); counter unit KB; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950 (FETCH_SIZE reports half the bytes of wide coalesced reads: MI355X_MICROARCH.md section HBM).",
