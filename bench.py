@@ -23,6 +23,7 @@ sys.path.insert(0, REPO)
 import gsdd_amd  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak
 # GSDD_ATTN_P -> (kernel template argument, what the softmax probabilities are carried as into the P.V product)
 P_MODES = {"a8": (8, "f16 hi (11 bits), + f16 lo (22 bits) in every (16-query, 32-key) tile that can hold a probability above 2^-8 of "
                      "its row's sum -- cleared by a ||q|| ||k|| bound where that proves it cannot, measured otherwise (logits error vs "
@@ -68,7 +69,31 @@ def profile_traffic(kernel, grid):
     return None, None
 
 
-def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
+def profile_counters(kernel, grid=None, regime="flat"):
+    """Issue-port / matrix-pipe occupancy of `kernel` from the newest profiles/r*_pmc_sq_counters.csv that lists it in the per-kernel
+    layout of tools/make_sq_csv.py (round 4 on): one row per (regime, kernel, grid), the means per dispatch of a rocprofv3 --pmc pass
+    over THIS program (`python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-extra`, started directly after `--`;
+    tools/profile_round.sh).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over the dispatch's SQ_BUSY_CYCLES / 32 shader engines;
+    valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 over the same.  Read, never typed in.  -> dict or None."""
+    import csv
+    import glob
+    want = kernel.replace(", ", ";").replace(" ", "")
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_sq_counters.csv")), reverse=True):
+        with open(f) as fh:
+            rows = [r for r in csv.DictReader(l for l in fh if not l.startswith("#"))]
+        if not rows or "valu_issue_busy" not in rows[0]:
+            continue
+        for r in rows:
+            if (r["kernel"].replace(" ", "").startswith(want) and r["regime"] == regime
+                    and (grid is None or int(r["grid_workgroups"]) == grid)):
+                out = {"mfma_busy": float(r["mfma_busy"]), "valu_issue_busy": float(r["valu_issue_busy"]),
+                       "valu_insts_per_dispatch": float(r["SQ_INSTS_VALU"]), "dispatches": int(r["dispatches"]),
+                       "grid_workgroups": int(r["grid_workgroups"]), "source": os.path.basename(f)}
+                return out
+    return None
+
+
+def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3, regime="flat"):
     """Per-launch timing of the kernels of a reverse step, live, with HIP events on the launch stream, in situ: right after the
     timed region `reps` more guided denoiser passes run eagerly as ONE full batch of 2B rows on one stream (the timed region
     itself may run two concurrent lanes, where a launch overlaps the other lane's kernels and its duration stops measuring the
@@ -121,8 +146,18 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
     flops = 16.0 * L * L * H * B2
     tf = flops / (ms * 1e-3) / 1e12
     traffic, src = profile_traffic(kernel, B2 * H * ((L + 255) // 256)) if (B2, L, H) == (32, 4096, 16) else (None, None)
-    roof = {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": src, "ms_per_launch": round(ms, 4),
+    full = (B2, L, H) == (32, 4096, 16)
+    ctr = profile_counters(kernel, B2 * H * ((L + 255) // 256), regime) if full else None
+    if ctr is not None:                           # one score = one (query, key) pair: 64 of them per wave-instruction slot
+        ctr["valu_insts_per_64_scores"] = round(ctr["valu_insts_per_dispatch"] / (float(L) * L * H * B2 / 64.0), 3)
+    # what the hardware says (the kernel issues bf16 / f16 MFMAs and is bound by the vector issue port of the f32 datapath: one v_exp_f32
+    # and the f32 -> f16 conversions per score): `achieved / peak / frac` stay the algorithmic f32-equivalent yardstick (16 L^2 FLOP per
+    # (sample, head) against the dense f32 matrix peak); `counters` carry the measured matrix-pipe and vector-issue occupancy, and
+    # `frac_of_bf16_mfma_peak` prices the same FLOPs against the 2.5 PFLOP/s of the pipe the MFMAs actually run on
+    roof = {"bound": "valu-issue (f32 datapath); matrix work on bf16/f16 MFMA", "kernel": kernel, "achieved": round(tf, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "peak_kind": "dense f32 matrix peak (f32-equivalent yardstick)", "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "frac_of_bf16_mfma_peak": round(tf / PEAK_BF16_MFMA_TFLOPS, 4),
+            "counters": ctr, "traffic": traffic, "traffic_source": src, "ms_per_launch": round(ms, 4),
             "launches_timed": n, "flops_per_launch": flops,
             "ms_by_block": [round(sum(e0.elapsed_ms(e1) for e0, e1 in events["attention"][i::n // reps]) / reps, 3) for i in range(n // reps)],
             "timed_as": f"one full batch of {B2} rows on one stream, after the timed region"}
@@ -131,20 +166,28 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
     Mrows = B2 * L
     ms, n = mean_ms("layer")                      # proj + MLP + next q|k|v (blocks 0..n-2: the full chain of four GEMMs)
     fl = 2.0 * (64 * 64 + 2 * 64 * 256 + 64 * 192) * Mrows
-    fam["gemm_family_fused_layer"] = {"bound": "mfma", "kernel": "d3pm_layer_h2_kernel<true, false>", "ms_per_launch": round(ms, 4),
+    fam["gemm_family_fused_layer"] = {"bound": "mfma (f16 hi + lo operands: 3 f16 MFMA products per f32-equivalent product)",
+                                      "kernel": "d3pm_layer_h2_kernel<true, false>", "ms_per_launch": round(ms, 4),
                                       "launches_timed": n, "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+                                      "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                                      "frac_of_bf16_mfma_peak": round(3 * fl / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                      "counters": profile_counters("d3pm_layer_h2_kernel<true;false>", None, regime) if full else None}
     ms, n = mean_ms("logits")
     fl = 2.0 * 64 * K * Mrows
-    fam["logits"] = {"bound": "mfma", "kernel": "d3pm_logits_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
+    fam["logits"] = {"bound": "mfma (bf16x3 operands: 6 bf16 MFMA products per f32-equivalent product) / hbm write",
+                     "kernel": "d3pm_logits_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
                      "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
-                     "hbm_write_GBs": round(Mrows * K * 4.0 / ms / 1e6, 1), "hbm_frac": round(Mrows * K * 4.0 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                     "frac_of_bf16_mfma_peak": round(6 * fl / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
+                     "hbm_write_GBs": round(Mrows * K * 4.0 / ms / 1e6, 1), "hbm_frac": round(Mrows * K * 4.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "counters": profile_counters("d3pm_logits_kernel", None, regime) if full else None}
     ms, n = mean_ms("step")
     by = 2.0 * M * K * 4
-    fam["posterior_step"] = {"bound": "hbm", "kernel": "d3pm_step_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
+    fam["posterior_step"] = {"bound": "hbm (streams both logits copies once); the f32 vector issue port is what limits it",
+                             "kernel": "d3pm_step_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
                              "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                             "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                             "counters": profile_counters("d3pm_step_kernel", None, regime) if full else None}
     # decode: the whole VQ-VAE decoder (implicit-GEMM convs), 221.0 GFLOP per 16x128x128 clip
     codes = torch.randint(0, K, (B,) + tuple(grid), device=device)
     vq.decode(codes)
@@ -157,9 +200,13 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3):
     ms = e0.elapsed_time(e1) / reps
     if tuple(grid) == (16, 16, 16):
         fl = 221.0e9 * B
-        fam["decode"] = {"bound": "mfma", "kernel": "gemm_kernel (VQ-VAE decoder, all launches)", "ms_per_call": round(ms, 3),
+        fam["decode"] = {"bound": "mfma (bf16x3 operands: 6 bf16 MFMA products per f32-equivalent product)",
+                         "kernel": "gemm_kernel (VQ-VAE decoder, all launches)", "ms_per_call": round(ms, 3),
                          "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+                         "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                         "frac_of_bf16_mfma_peak": round(6 * fl / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
+                         # the decoder's dominant launch (the 256 -> 256 transposed-conv phases at 64x64 / 32x32)
+                         "counters": profile_counters("gemm_kernel<128;true;256;512>", None, regime)}
     return roof, fam
 
 
@@ -203,6 +250,98 @@ def cpu_baseline(args, dm, vq, L):
     return out
 
 
+def other_configs(args, dm, vq, device):
+    """BASELINE.json's other single-GPU configurations, outside the timed headline, each one warm-up + timed repetitions in this
+    process so that the driver's run carries their numbers: C2 = VQ-VAE training step (bs 64, 16x128x128 clips, 256 channels, 3
+    residual blocks, 4096 codes; forward with batch statistics + codebook EMA, full backward, Adam; 88.5 TFLOP per step, SURVEY.md
+    section 8(d)), C4 = D3PM training step at its per-GPU shape (bs 16 of the global 128; q_sample, 19-layer denoiser forward +
+    backward, loss, Adam; 16 x 278 GFLOP = 4.45 TFLOP), C5 = text-conditioned sampling at its per-GPU shape (bs 8 of the global 64:
+    captions -> text provider -> DiscreteDiffusion(zero_text_emb=False).sample_videos -> decode).  Synthetic data, random-init weights."""
+    import statistics
+    out = {}
+
+    def timeit(fn, warm, n):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    try:                                                             # ---- C5 per rank (before anything touches dm's weights)
+        sys.path.insert(0, REPO)
+        from src.models.text_models.clip_text_embedding import CLIPTextEmbedding
+        dd = gsdd_amd.DiscreteDiffusion(CLIPTextEmbedding(clip_dim=512), dm, zero_text_emb=False).to(device).eval()
+        rank5, b5 = 5, 8
+        texts = [f"a person is doing activity number {rank5 * b5 + i}" for i in range(b5)]
+        keep = (dm.noise_seed, dm.noise_stream, dm.row_offset)
+        dm.set_noise(1234, 0, row_offset=rank5 * b5)
+        ts = timeit(lambda: dd.sample_videos(texts, vq), 1, 2)
+        dm.set_noise(*keep)
+        out["c5_rank"] = {"workload": "C5 per GPU: MSR-VTT-shaped text-conditioned 100-step sample, bs 8 (64 sharded x8), guidance 2, "
+                                      "L=4096, K=4096, 19 layers + decode; text provider = deterministic stand-in (CLIP ViT-B/32 is not "
+                                      "obtainable offline)",
+                          "value": round(b5 / statistics.mean(ts), 4), "unit": "videos/s", "s_per_pass": [round(t, 4) for t in ts],
+                          "sampler_lanes": dm._last_lanes, "guidance_copies": 1 if dm._last_cfg_dedupe else 2,
+                          "frac_f32_matrix_peak": round(b5 * 18.76 / statistics.mean(ts) / PEAK_F32_MFMA_TFLOPS, 4)}
+    except Exception as e:                                           # noqa: BLE001
+        out["c5_rank"] = {"error": f"{type(e).__name__}: {e}"}
+
+    try:                                                             # ---- C4 per rank
+        from gsdd_amd.d3pm_train import D3PMTrainer
+        targs = argparse.Namespace(**vars(args))
+        dmt, _, L = build_models(targs, device)
+        dmt.train()
+        trainer = D3PMTrainer(dmt, lr=1e-4)
+        b4 = 16
+        g = torch.Generator().manual_seed(1)
+        tok = torch.randint(0, args.codes, (b4, L), generator=g).to(device)
+        cond4 = torch.zeros(b4, 1, 512, device=device)               # the reference's zeroed text embedding (discrete_diffusion.py:25)
+        losses = []
+        ts = timeit(lambda: losses.append(trainer.step(tok, cond4)), 2, 3)
+        ms = statistics.median(ts) * 1e3
+        tflop = b4 * 0.278
+        out["c4"] = {"workload": "C4 per GPU: D3PM training step, bs 16 (global 128 on 8 GPUs), 16x16x16 tokens, K=4096, 19 layers, "
+                                 "T=100: q_sample + forward + loss + backward + Adam", "ms_per_step": round(ms, 2),
+                     "ms_each": [round(t * 1e3, 2) for t in ts], "samples_per_s": round(b4 / ms * 1e3, 2), "tflop_per_step": tflop,
+                     "achieved_tflops": round(tflop / ms * 1e3, 2), "frac_f32_matrix_peak": round(tflop / ms * 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "loss_first_last": [round(float(losses[0][0]), 4), round(float(losses[-1][0]), 4)],
+                     "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        del trainer, dmt
+    except Exception as e:                                           # noqa: BLE001
+        out["c4"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+
+    try:                                                             # ---- C2
+        from gsdd_amd.vqvae_trainer import VQVAETrainer
+        torch.manual_seed(0)
+        vqt = gsdd_amd.VQVAE(None, 128, args.codes, 256, 3, [1, 8, 8], 16, 128).to(device).train()
+        trainer = VQVAETrainer(vqt, lr=4e-4)
+        b2 = 64
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn((b2, 3, 16, 128, 128), generator=g).to(device)
+        recon = []
+        torch.cuda.reset_peak_memory_stats()
+        ts = timeit(lambda: recon.append(trainer.step(x)["recon_loss"]), 1, 2)
+        sec = statistics.mean(ts)
+        out["c2"] = {"workload": "C2: VQ-VAE training step, bs 64, UCF101-shaped synthetic 16x128x128 clips, n_hiddens 256, "
+                                 "n_res_layers 3, 4096 codes: forward (batch statistics, codebook EMA) + backward + Adam",
+                     "s_per_step": round(sec, 4), "s_each": [round(t, 4) for t in ts], "clips_per_s": round(b2 / sec, 2),
+                     "tflop_per_step": 88.5, "achieved_tflops": round(88.5 / sec, 2),
+                     "frac_f32_matrix_peak": round(88.5 / sec / PEAK_F32_MFMA_TFLOPS, 4),
+                     "recon_loss": [round(float(r), 4) for r in recon],
+                     "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        del trainer, vqt, x
+    except Exception as e:                                           # noqa: BLE001
+        out["c2"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    return out
+
+
 LAYER_ARITH = {
     "h2": "per-block GEMMs (proj, MLP, next q|k|v): operands as f16 hi + lo (22 bits, every product exact in the f32 accumulator; "
           "as accurate as an f32 GEMM: DESIGN.md section 4; GSDD_LAYER=x3p selects the bf16x3 kernel)",
@@ -241,7 +380,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=2, help="concurrent sub-batches of the sampler on separate HIP streams (the sampler's "
                                                         "default: two when the batch allows it; tokens do not depend on it)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side regimes (trained-like weights, zero cond)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side regimes (trained-like weights, zero cond) and the other configs")
+    ap.add_argument("--trained-like", action="store_true", help="profiling passes only: run the whole bench on weights of a trained-like "
+                                                                "magnitude (peaky softmax rows) instead of the reference init")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,6 +406,8 @@ def main():
     device = torch.device("cuda", local)
 
     dm, vq, L = build_models(args, device)
+    if args.trained_like:
+        trained_like_weights(dm)
     B = args.batch
     texts = ["synthetic"] * B
     g = torch.Generator().manual_seed(100 + rank)
@@ -323,6 +466,7 @@ def main():
                                    f"{args.grid[1] * 8}x{args.grid[2] * 8}",
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "hipgraph": not args.no_graph, "sampler_lanes": lanes_used,
+                       "weights": "trained-like magnitude (--trained-like)" if args.trained_like else "reference init N(0, 0.02)",
                        "arith": "f32 results; QK^T, to_logits and VQ-VAE GEMM operands as error-free 3-way bf16 splits on the matrix "
                                 "pipe (dropped terms < 2^-24); " + LAYER_ARITH[os.environ.get("GSDD_LAYER", "h2")] +
                                 "; softmax P: " + P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][1]},
@@ -331,7 +475,8 @@ def main():
         }
         # the two side measurements must never cost the run its JSON line
         try:
-            line["roofline"], families = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid)
+            line["roofline"], families = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid,
+                                                   regime="trained_like" if args.trained_like else "flat")
         except Exception as e:                                   # noqa: BLE001
             line["roofline"], families = {"error": f"{type(e).__name__}: {e}"}, None
         if world == 1 and not args.no_cpu_baseline:
@@ -361,6 +506,7 @@ def main():
                 extra = {"unit": "videos/s", "redo_chunks_headline": headline_redo}
                 if families is not None:
                     extra["roofline_families"] = families
+                extra["configs"] = other_configs(args, dm, vq, device)
                 extra["zero_cond"], extra["redo_chunks_zero_cond"] = timed(torch.zeros_like(cond))
                 extra["zero_cond_guidance_copies"] = 1 if getattr(dm, "_last_cfg_dedupe", False) else 2
                 other = 1 if lanes_used > 1 else 2
@@ -370,8 +516,9 @@ def main():
                 trained_like_weights(dm)
                 extra["trained_like"], extra["redo_chunks_trained_like"] = timed(cond)
                 try:
-                    roof_t, _ = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid, reps=1)
+                    roof_t, _ = rooflines(dm, vq, cond, cf_cond, B, L, 16, device, args.codes, args.grid, reps=1, regime="trained_like")
                     extra["trained_like_attention_ms_per_launch"] = roof_t["ms_per_launch"]
+                    extra["trained_like_attention_counters"] = roof_t["counters"]
                     extra["trained_like_attention_ms_by_block"] = roof_t["ms_by_block"]       # blocks 1..18 (block 0 is a half batch)
                 except Exception:                                # noqa: BLE001
                     pass

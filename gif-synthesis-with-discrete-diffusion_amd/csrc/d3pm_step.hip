@@ -41,7 +41,11 @@ __device__ __forceinline__ float exp_le0(float x) {
 // the end of the step does not see; what its accuracy decides is how often x - lse rounds to the neighbouring float.  With these
 // terms the fp64 sum over a row is accurate to ~1e-9 relative (the largest term is exp(0) = 1 exactly), the same as with the
 // 12-instruction exp_le0, which is kept for the per-class values (log_add_exp), where every class has its own error.
+#ifdef GSDD_DEV_EXACT_SUM_EXP      // development A/B only (tools/neartie_diff.py): the sum terms on the library-exact exponential, as before 2f17ed5
+__device__ __forceinline__ float exp_term(float d) { return exp_le0(d); }
+#else
 __device__ __forceinline__ float exp_term(float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896340736f); }
+#endif
 __device__ __forceinline__ float log_norm(float x) {
     const float LN2_HI = __builtin_bit_cast(float, 0x3f317217u), LN2_LO = __builtin_bit_cast(float, 0x3377d1cfu);
     const float r = __builtin_amdgcn_logf(x);

@@ -220,3 +220,39 @@ def test_headline_shape_tokens(G):
                                             "lanes2_equals_lanes1": True, "max_token": int(tok.max()),
                                             "distinct_codes": int(tok.unique().numel()), "redo_events": dm.attention_redo_events()})
     assert all(v == 0 for v in mism.values()), mism
+
+
+def test_c5_rank_shape_text_conditioned_sampling(G):
+    """Config C5 at its per-GPU shape (MSR-VTT text-conditioned sample, bs 64 sharded over 8 GPUs = 8 clips per rank; here rank 5):
+    captions -> CLIPTextEmbedding (the deterministic stand-in: the real tower is not obtainable offline) ->
+    DiscreteDiffusion(zero_text_emb=False).sample_videos -> two sampler lanes of 4 clips, L = 4096, K = 4096, 19 layers, 100
+    graph-replayed guided steps -> VQ-VAE decode.  Rows 0 / 3 / 7 of the rank's batch equal three B = 1 runs keyed as global rows
+    8 * 5 + {0, 3, 7} (the property that makes the 8-way shard reproduce the bs-64 run: discrete_diffusion.py:44-62), every token is a
+    code, and the decoded clips are finite and have the clip shape."""
+    from src.models.text_models.clip_text_embedding import CLIPTextEmbedding
+    dm = full_d3pm(G, 0, False)
+    torch.manual_seed(1)
+    vq = G.VQVAE(None, 128, 4096, 256, 3, [1, 8, 8], 16, 128).eval()
+    dd = G.DiscreteDiffusion(CLIPTextEmbedding(clip_dim=512), dm, zero_text_emb=False).cuda().eval()
+    vq = vq.cuda()
+    rank, B, K = 5, 8, 4096
+    texts = [f"a person is doing activity number {rank * B + i}" for i in range(B)]
+    emb = dd.get_text_embeddings(texts)
+    assert tuple(emb.shape) == (B, 1, 512) and float(emb.abs().max()) > 0             # the captions do condition the denoiser
+    dm.set_noise(4321, 0, row_offset=rank * B)
+    clips = dd.sample_videos(texts, vq)
+    tok = dd.last_content_token.cpu()
+    assert dm._last_lanes == 2 and not dm._last_cfg_dedupe                               # two lanes of 4, both guidance copies ran
+    assert tuple(clips.shape) == (B, 3, 16, 128, 128) and bool(torch.isfinite(clips).all())
+    assert tok.dtype == torch.int64 and int(tok.min()) >= 0 and int(tok.max()) < K
+    mism = {}
+    for r in (0, 3, 7):
+        dm.set_noise(4321, 0, row_offset=rank * B + r)
+        one = dd.sample_videos(texts[r:r + 1], vq)
+        mism[r] = int((dd.last_content_token.cpu()[0] != tok[r]).sum())
+        assert torch.equal(one[0], clips[r]), f"decoded clip of row {r} differs from its single-row run"
+    parity_report("c5_rank_shape_text_conditioned", {"rank": rank, "B": B, "rows_checked": list(mism),
+                                                     "mismatches_vs_single_row_runs": list(mism.values()),
+                                                     "distinct_codes": int(tok.unique().numel()), "max_token": int(tok.max()),
+                                                     "clip_abs_max": float(clips.abs().max()), "redo_events": dm.attention_redo_events()})
+    assert all(v == 0 for v in mism.values()), mism
