@@ -34,6 +34,11 @@ P_MODES = {"a8": (8, "f16 hi (11 bits), + f16 lo (22 bits) in every (16-query, 3
 HBM_PEAK_GBS = 8000.0
 
 
+def attention_mode_name(dm):
+    """'a8' | '22' | '11' | 'a12': what the sampler's attention launches run as at L >= 2048 (module attribute, else GSDD_ATTN_P, else a8)."""
+    return str(dm.transformer.attention_mode or os.environ.get("GSDD_ATTN_P", "a8"))
+
+
 def build_models(args, device):
     torch.manual_seed(0)
     L = args.grid[0] * args.grid[1] * args.grid[2]
@@ -140,7 +145,7 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3, regime="f
         ev = events[name]
         return sum(e0.elapsed_ms(e1) for e0, e1 in ev) / len(ev), len(ev)
 
-    pm = P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][0]
+    pm = P_MODES[attention_mode_name(dm)][0]
     kernel = f"d3pm_attention_v4_kernel<384, {pm}>"
     ms, n = mean_ms("attention")
     flops = 16.0 * L * L * H * B2
@@ -174,11 +179,10 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3, regime="f
                                       "counters": profile_counters("d3pm_layer_h2_kernel<true;false>", None, regime) if full else None}
     ms, n = mean_ms("logits")
     fl = 2.0 * 64 * K * Mrows
-    fam["logits"] = {"bound": "mfma (bf16x3 operands: 6 bf16 MFMA products per f32-equivalent product) / hbm write",
+    fam["logits"] = {"bound": "mfma (exact f32: v_mfma_f32_32x32x2_f32, the f32 datapath's own peak) / hbm write",
                      "kernel": "d3pm_logits_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
                      "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
-                     "frac_of_bf16_mfma_peak": round(6 * fl / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
                      "hbm_write_GBs": round(Mrows * K * 4.0 / ms / 1e6, 1), "hbm_frac": round(Mrows * K * 4.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "counters": profile_counters("d3pm_logits_kernel", None, regime) if full else None}
     ms, n = mean_ms("step")
@@ -346,8 +350,6 @@ LAYER_ARITH = {
     "h2": "per-block GEMMs (proj, MLP, next q|k|v): operands as f16 hi + lo (22 bits, every product exact in the f32 accumulator; "
           "as accurate as an f32 GEMM: DESIGN.md section 4; GSDD_LAYER=x3p selects the bf16x3 kernel)",
     "x3p": "per-block GEMMs as 3-way bf16 splits too (GSDD_LAYER=x3p)",
-    "x3": "per-block GEMMs as 3-way bf16 splits, split on the fly (GSDD_LAYER=x3)",
-    "f32": "per-block GEMMs on v_mfma_f32_32x32x2_f32 (GSDD_LAYER=f32)",
 }
 
 
@@ -381,6 +383,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="concurrent sub-batches of the sampler on separate HIP streams (the sampler's "
                                                         "default: two when the batch allows it; tokens do not depend on it)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side regimes (trained-like weights, zero cond) and the other configs")
+    ap.add_argument("--attention-mode", default=None, choices=["a8", "22", "11", "a12"],
+                    help="softmax P format of the sampler's attention (default: the library's, a8 at this length); DESIGN.md section 4")
     ap.add_argument("--trained-like", action="store_true", help="profiling passes only: run the whole bench on weights of a trained-like "
                                                                 "magnitude (peaky softmax rows) instead of the reference init")
     args = ap.parse_args()
@@ -408,6 +412,7 @@ def main():
     dm, vq, L = build_models(args, device)
     if args.trained_like:
         trained_like_weights(dm)
+    dm.transformer.attention_mode = args.attention_mode
     B = args.batch
     texts = ["synthetic"] * B
     g = torch.Generator().manual_seed(100 + rank)
@@ -467,9 +472,9 @@ def main():
                        "global_batch": B * world, "parallelism": f"replicas x{world} (batch-sharded, no collective)",
                        "hipgraph": not args.no_graph, "sampler_lanes": lanes_used,
                        "weights": "trained-like magnitude (--trained-like)" if args.trained_like else "reference init N(0, 0.02)",
-                       "arith": "f32 results; QK^T, to_logits and VQ-VAE GEMM operands as error-free 3-way bf16 splits on the matrix "
-                                "pipe (dropped terms < 2^-24); " + LAYER_ARITH[os.environ.get("GSDD_LAYER", "h2")] +
-                                "; softmax P: " + P_MODES[os.environ.get("GSDD_ATTN_P", "a8")][1]},
+                       "arith": "f32 results; QK^T and VQ-VAE GEMM operands as error-free 3-way bf16 splits on the matrix pipe (dropped "
+                                "terms < 2^-24); to_logits on the exact-f32 matrix instruction; " +
+                                LAYER_ARITH[os.environ.get("GSDD_LAYER", "h2")] + "; softmax P: " + P_MODES[attention_mode_name(dm)][1]},
             "ranks": {"seconds_max": round(max(rank_s), 4), "seconds_min": round(min(rank_s), 4),
                       "videos_per_s_per_rank": [round(B * args.steps / s_, 4) for s_ in rank_s]},
         }
@@ -522,6 +527,12 @@ def main():
                     extra["trained_like_attention_ms_by_block"] = roof_t["ms_by_block"]       # blocks 1..18 (block 0 is a half batch)
                 except Exception:                                # noqa: BLE001
                     pass
+                # the same trained-like weights with P = f16 hi only in every tile (attention_mode '11': data-independent cost, the
+                # documented fast mode whose error is pinned by tests/test_gpu_fullsize.py::test_attention_mode_p11_contract)
+                if dm.transformer.attention_mode is None:
+                    dm.transformer.attention_mode = "11"
+                    extra["trained_like_p11"], _ = timed(cond)
+                    dm.transformer.attention_mode = None
                 line["extra"] = extra
             except Exception as e:                               # noqa: BLE001
                 line["extra"] = {"error": f"{type(e).__name__}: {e}"}

@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("ln_stride", _i), ("rows_per_batch", _i),
         ("epi_scale", _p), ("epi_shift", _p), ("bvec", _p), ("act", _i), ("residual", _p),
         ("out", _p), ("oD", _i), ("oH", _i), ("oW", _i), ("osd", _i), ("osh", _i), ("osw", _i),
-        ("ood", _i), ("ooh", _i), ("oow", _i), ("out_pitch", _i), ("out_mode", _i),
+        ("ood", _i), ("ooh", _i), ("oow", _i), ("out_pitch", _i), ("out_mode", _i), ("flags", _i),
     ]
 
 
@@ -46,7 +46,7 @@ class StepDesc(C.Structure):
         ("logits_c", _p), ("logits_u", _p), ("tok_in", _p), ("tok_out", _p),
         ("B", _i), ("L", _i), ("K", _i), ("T", _i), ("guidance", C.c_float),
         ("sched", _p * 8), ("t_dev", _p), ("seed", C.c_uint64), ("stream_dev", _p), ("row0", _i64),
-        ("post_dbg", _p), ("x0_dbg", _p),
+        ("post_dbg", _p), ("x0_dbg", _p), ("occupancy", _i),
     ]
 
 
@@ -65,8 +65,17 @@ class LayerDesc(C.Structure):
         ("y", _p), ("x", _p), ("M", _i64), ("L", _i), ("n_embd", _i), ("hidden", _i), ("cvec", _p),
         ("wproj", _p), ("bproj", _p), ("ln2_g", _p), ("ln2_b", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p),
         ("ada", _p), ("t2", _p), ("wqkv", _p), ("bqkv", _p), ("qkv", _p), ("w2_x3", _p), ("wqkv_x3", _p), ("kv_img", _p),
-        ("layer_h2", _p), ("wqkv_h2", _p), ("range_flag", _p),
+        ("layer_h2", _p), ("wqkv_h2", _p), ("variant", _i), ("range_flag", _p),
     ]
+
+
+# variant / mode arguments of include/gsdd.h (GSDD_*): the library reads no environment variable; ops.py maps the debugging
+# environment switches onto these
+GEMM_EXACT_F32 = 1
+AXIAL_AUTO, AXIAL_VALU = 0, 1
+ATTN_AUTO, ATTN_P22, ATTN_P11, ATTN_A8, ATTN_A12, ATTN_F32PV, ATTN_KC256 = range(7)
+LAYER_AUTO, LAYER_X3P, LAYER_H2 = 0, 2, 3
+ATTN_BWD_AUTO, ATTN_BWD_VALU, ATTN_BWD_SPLIT, ATTN_BWD_FQC64, ATTN_BWD_FQC128, ATTN_BWD_NW8, ATTN_BWD_DBG1, ATTN_BWD_DBG2 = range(8)
 
 
 class GsddError(RuntimeError):
@@ -86,7 +95,7 @@ def lib():
         L.gsdd_row_stats.argtypes = [_p, _i64, _i, C.c_float, _p, _p]
         L.gsdd_ncdhw_to_rows.argtypes = [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]
         L.gsdd_preprocess_clip.argtypes = [_p] + [_i] * 10 + [_p, _p]
-        L.gsdd_axial_attention.argtypes = [_p, _i, _i, _i, _i, _i, _i, _p, _p]
+        L.gsdd_axial_attention.argtypes = [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p]
         L.gsdd_pool3d.argtypes = [_p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _p, _i, _p]
         L.gsdd_nearest_code.argtypes = [_p, _i64, _i, _p, _i, _p, _p, _p, _i64, _p]
         L.gsdd_nearest_code_workspace_bytes.argtypes = [_i]
@@ -100,14 +109,14 @@ def lib():
         L.gsdd_bn_relu_bwd.argtypes = [_p, _p, _i64, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]
         L.gsdd_relu_mask.argtypes = [_p, _p, _p, _i64, _p]
         L.gsdd_lincomb.argtypes = [_p, _p, _p, C.c_float, _p, _i64, _p]
-        L.gsdd_axial_attention_bwd.argtypes = [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]
+        L.gsdd_axial_attention_bwd.argtypes = [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]
         L.gsdd_codebook_ema.argtypes = [_p, _p, _i64, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p, _i, _p]
         L.gsdd_code_perplexity.argtypes = [_p, _i, _i64, _p, _p]
         L.gsdd_mse.argtypes = [_p, _p, _i64, C.c_float, _p, _p, _i64, _p]
         L.gsdd_d3pm_embed.argtypes = [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p]
         L.gsdd_adaln_table.argtypes = [_p, _i, _i, _p, _p, _p, _p]
         L.gsdd_small_linear.argtypes = [_p, _i, _i, _p, _p, _i, _p, _p]
-        L.gsdd_d3pm_attention.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _p, _p]
+        L.gsdd_d3pm_attention.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _p, _i, _p]
         L.gsdd_d3pm_attention_workspace_bytes.argtypes = [_i, _i, _i]
         L.gsdd_d3pm_attention_workspace_bytes.restype = _i64
         L.gsdd_d3pm_layer.argtypes = [C.POINTER(LayerDesc), _p]
@@ -128,8 +137,8 @@ def lib():
         L.gsdd_wgrad.argtypes = [_p, _i, _p, _i, _i64, _i, _i, _p, _p, _p]
         L.gsdd_colsum.argtypes = [_p, _i, _i64, _i, _p, _p]
         L.gsdd_batch_rowsum.argtypes = [_p, _i, _i, _i, _p, _p]
-        L.gsdd_d3pm_attention_train.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _p]
-        L.gsdd_d3pm_attention_bwd.argtypes = [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _p]
+        L.gsdd_d3pm_attention_train.argtypes = [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _i, _p]
+        L.gsdd_d3pm_attention_bwd.argtypes = [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i64, _i, _p]
         L.gsdd_d3pm_attention_bwd_workspace_bytes.argtypes = [_i, _i, _i]
         L.gsdd_d3pm_attention_bwd_workspace_bytes.restype = _i64
         L.gsdd_d3pm_embed_bwd.argtypes = [_p, _p, _i, _i, _i, _i, _p, _p, _p]

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/gsdd.h"
@@ -31,15 +32,26 @@ void set_error(const std::string& s);
 
 #define GSDD_CHECK_LAUNCH() GSDD_CHECK_HIP(hipGetLastError())
 
-// true the first time a call site runs on the current device (hipFuncSetAttribute for dynamic LDS is per device)
-inline bool first_on_device(unsigned long long& mask) {
+// Per-device, per-call-site set-up (hipFuncSetAttribute for dynamic LDS above 64 KB is per device).  The call site's mask holds one bit per
+// device; a bit is set only AFTER every call of the set-up body has succeeded, so a failed hipFuncSetAttribute is reported by this call
+// and retried by the next one instead of surfacing later as an opaque launch error.  Atomic: two host threads may race through the body
+// (the attribute calls are idempotent), neither can skip it before it has succeeded once.
+inline bool device_setup_pending(const std::atomic<unsigned long long>& mask, unsigned long long& bit) {
     int dev = 0;
+    bit = 0ull;
     if (hipGetDevice(&dev) != hipSuccess) return true;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (mask & bit) return false;
-    mask |= bit;
-    return true;
+    bit = 1ull << (dev & 63);
+    return (mask.load(std::memory_order_acquire) & bit) == 0ull;
 }
+#define GSDD_ONCE_PER_DEVICE(mask_name, ...)                                   \
+    do {                                                                       \
+        static std::atomic<unsigned long long> mask_name{0ull};                \
+        unsigned long long bit_ = 0ull;                                        \
+        if (::gsdd::device_setup_pending(mask_name, bit_)) {                   \
+            __VA_ARGS__                                                        \
+            mask_name.fetch_or(bit_, std::memory_order_release);               \
+        }                                                                      \
+    } while (0)
 
 constexpr int WAVE = 64;
 

@@ -802,13 +802,16 @@ using namespace gsdd;
 // L >= 2048, hi + lo everywhere below that: the rounding errors of the skipped lo halves average out over the keys of a row, as
 // 1.4e-4 * sqrt(L - 256) / L for flat rows -- 2.1e-6 rms at L = 4096, but 3.8e-6 at L = 1024 (measured maximum 2.5e-5, above the
 // 2e-5 this kernel is held to), and short sequences have too few chunks to gain anything.
-// GSDD_ATTN_P=22 -> 1 (hi + lo everywhere: the most exact variant), 11 -> 0 (hi only), a8 / a12 -> adaptive with threshold
-// 2^-8 / 2^-12 at any L.  Read on every call (cheap) so that one process can measure all of them.  Errors and times: DESIGN.md.
-static int attn_p_mode(int L) {
-    const char* e = getenv("GSDD_ATTN_P");
-    if (e == nullptr) return L >= 2048 ? 8 : 1;
-    if (e[0] == 'a') return atoi(e + 1) == 12 ? 12 : 8;
-    return atoi(e) == 11 ? 0 : 1;
+// The caller picks per call (`mode`, include/gsdd.h): GSDD_ATTN_P22 -> 1 (hi + lo everywhere: the most exact variant), GSDD_ATTN_P11 -> 0
+// (hi only), GSDD_ATTN_A8 / _A12 -> adaptive with threshold 2^-8 / 2^-12 at any L.  Errors and times: DESIGN.md.
+static int attn_p_mode(int mode, int L) {
+    switch (mode) {
+        case GSDD_ATTN_P22: return 1;
+        case GSDD_ATTN_P11: return 0;
+        case GSDD_ATTN_A8: return 8;
+        case GSDD_ATTN_A12: return 12;
+        default: return L >= 2048 ? 8 : 1;
+    }
 }
 
 extern "C" int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H) {
@@ -820,16 +823,16 @@ int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, i
                         void* stream);                                                              // d3pm_bwd.hip
 
 extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
-                                   void* workspace, int64_t workspace_bytes, uint64_t* redo_events, void* stream) {
+                                   void* workspace, int64_t workspace_bytes, uint64_t* redo_events, int mode, void* stream) {
     GSDD_CHECK_ARG(q && out && ((k == nullptr) == (v == nullptr)), "null pointer");
+    GSDD_CHECK_ARG(mode >= GSDD_ATTN_AUTO && mode <= GSDD_ATTN_KC256, "mode: one of GSDD_ATTN_*");
     GSDD_CHECK_ARG(B > 0 && H > 0 && L > 0, "bad sizes");
     GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
     const bool premade = k == nullptr;        // the workspace already holds the K / V images (gsdd_d3pm_layer wrote them)
-    static const bool force_v3e = getenv("GSDD_ATTN_V3") != nullptr;
-    GSDD_CHECK_ARG(!premade || (L % 32 == 0 && workspace != nullptr && !force_v3e), "k = v = NULL needs the matrix-pipe kernel's images in the workspace");
+    const bool force_v3 = mode == GSDD_ATTN_F32PV;     // exact-f32 P.V (mfma 4x4x1) kernel, no workspace use
+    GSDD_CHECK_ARG(!premade || (L % 32 == 0 && workspace != nullptr && !force_v3), "k = v = NULL needs the matrix-pipe kernel's images in the workspace");
     if (L % 16 != 0) return gsdd_attention_valu(q, k, v, B, L, H, out, nullptr, stream);     // ragged lengths: VALU kernel
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
-    static const bool force_v3 = getenv("GSDD_ATTN_V3") != nullptr;    // A/B switch: exact-f32 P.V (mfma 4x4x1) variant
     hipStream_t st = (hipStream_t)stream;
     if (L % 32 == 0 && !force_v3 && workspace != nullptr) {
         GSDD_CHECK_ARG(workspace_bytes >= gsdd_d3pm_attention_workspace_bytes(B, L, H), "workspace too small");
@@ -843,8 +846,8 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
             hipLaunchKernelGGL(d3pm_attn_prep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, k, v, rows, kp, vp, kn, ksm);
             GSDD_CHECK_LAUNCH();
         }
-        static const bool kc256 = getenv("GSDD_ATTN_KC") != nullptr && atoi(getenv("GSDD_ATTN_KC")) == 256;
-        const int pmode = attn_p_mode(L);
+        const bool kc256 = mode == GSDD_ATTN_KC256;          // development variant: 256-key chunks, hi + lo everywhere
+        const int pmode = attn_p_mode(mode, L);
         float* nolse = nullptr;
         if (kc256) hipLaunchKernelGGL(d3pm_attention_v4_kernel<256>, grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
         else if (pmode == 0) hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 0>), grid, dim3(256), 0, st, q, kp, vp, kn, ksm, B, L, H, out, nolse, redo);
@@ -861,8 +864,10 @@ extern "C" int gsdd_d3pm_attention(const float* q, const float* k, const float* 
 // Training forward on the same matrix-pipe kernel: also writes the log2-domain log-sum-exp the backward kernels consume.
 // Returns GSDD_OK and sets *done = 1 when the fast path applies (L % 32 == 0 and a workspace was given).
 int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
-                               void* workspace, int64_t workspace_bytes, void* stream, int* done) {
+                               void* workspace, int64_t workspace_bytes, int mode, void* stream, int* done) {
     *done = 0;
+    GSDD_CHECK_ARG(mode == GSDD_ATTN_AUTO || mode == GSDD_ATTN_P22 || mode == GSDD_ATTN_A8,
+                   "training forward: mode is GSDD_ATTN_AUTO, GSDD_ATTN_P22 or GSDD_ATTN_A8");
     if (L % 32 != 0 || workspace == nullptr) return GSDD_OK;
     GSDD_CHECK_ARG(workspace_bytes >= gsdd_d3pm_attention_workspace_bytes(B, L, H), "workspace too small");
     GSDD_CHECK_ARG((int64_t)B * H * ((L + 255) / 256) < (1ll << 31), "grid too large");
@@ -877,10 +882,9 @@ int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, i
     GSDD_CHECK_LAUNCH();
     // The training forward uses the sampler's adaptive lo half at L >= 2048 (the norm-bound form: on flat rows every tile is cleared a
     // priori): its output error <= 2e-5 of the row scale is below what the gradient parity tests resolve (full-size gradient parity and
-    // the 2e-5 attention-backward bar pass unchanged) and the step is 3.2 ms shorter (64.6 -> 61.4 ms).  GSDD_ATTN_TRAIN_P=22: hi + lo
-    // everywhere, the round-2 behaviour.
-    const char* tp = getenv("GSDD_ATTN_TRAIN_P");
-    if (!(tp != nullptr && atoi(tp) == 22) && L >= 2048)
+    // the 2e-5 attention-backward bar pass unchanged) and the step is 3.2 ms shorter (64.6 -> 61.4 ms).  mode GSDD_ATTN_P22: hi + lo
+    // everywhere, the round-2 behaviour; GSDD_ATTN_A8: adaptive at any L.
+    if (mode == GSDD_ATTN_A8 || (mode == GSDD_ATTN_AUTO && L >= 2048))
         hipLaunchKernelGGL((d3pm_attention_v4_kernel<384, 8>), dim3((unsigned)(B * H * ((L + 255) / 256))), dim3(256), 0, st, q, kp, vp, kn, ksm,
                            B, L, H, out, lse, noredo);
     else

@@ -760,7 +760,7 @@ extern "C" int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H) 
 
 // Matrix-pipe backward; returns GSDD_OK with *done = 0 when the shape needs the VALU kernels (L % 32 != 0 or no workspace).
 int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse, int B,
-                            int L, int H, float* dqkv, void* workspace, int64_t workspace_bytes, void* stream, int* done) {
+                            int L, int H, float* dqkv, void* workspace, int64_t workspace_bytes, int variant, void* stream, int* done) {
     *done = 0;
     if (L % 32 != 0 || workspace == nullptr) return GSDD_OK;
     GSDD_CHECK_ARG(workspace_bytes >= gsdd_d3pm_attention_bwd_workspace_bytes(B, L, H), "workspace too small");
@@ -776,7 +776,7 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     im.qv = w; w += rows * 2;
     im.gv = w;
     hipStream_t st = (hipStream_t)stream;
-    const bool split_kernels = getenv("GSDD_ATTN_BWD_SPLIT") != nullptr;            // A/B switch (read per call): dQ kernel + dK/dV kernel
+    const bool split_kernels = variant == GSDD_ATTN_BWD_SPLIT;                      // development variant: dQ kernel + dK/dV kernel
     if (!split_kernels && H == 16 && M % 16 == 0)
         hipLaunchKernelGGL(attn_bwd_prep_fused_kernel, dim3((unsigned)(M / 16)), dim3(256), 0, st, q, o, dO, lse, M, im);
     else
@@ -786,8 +786,7 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     const dim3 grid((unsigned)(B * H * ((L + 255) / 256)));
     if (!split_kernels) {
         float* dq_part = reinterpret_cast<float*>(reinterpret_cast<uint4*>(workspace) + rows * 16);
-        static unsigned long long fattr_done = 0ull;      // one bit per device: the attribute is per device
-        if (first_on_device(fattr_done)) {
+        GSDD_ONCE_PER_DEVICE(fattr_done,
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sizeof(FusedSmem<4, 128>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -800,13 +799,12 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
                                                (int)sizeof(FusedSmem<4, 64>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sizeof(FusedSmem<4, 96>)));
-        }
-        const char* dbg = getenv("GSDD_FUSED_DBG");
-        const int dbgv = dbg ? atoi(dbg) : 0;
-        const char* fqe = getenv("GSDD_ATTN_BWD_FQC");                // A/B switch (read per call): queries per LDS chunk, 96 (default), 64, 128
-        const int fqc = fqe != nullptr ? atoi(fqe) : 96;
-        const char* nwe = getenv("GSDD_ATTN_BWD_NW");                 // A/B switch (read per call): waves per workgroup, 4 (default) or 8
-        const int nw = (dbgv == 0 && nwe != nullptr && atoi(nwe) == 8) ? 8 : 4;
+        );
+        // development variants (include/gsdd.h): debug stages of the fused kernel, queries per LDS chunk 96 (default) / 64 / 128, waves per
+        // workgroup 4 (default) or 8
+        const int dbgv = variant == GSDD_ATTN_BWD_DBG1 ? 1 : (variant == GSDD_ATTN_BWD_DBG2 ? 2 : 0);
+        const int fqc = variant == GSDD_ATTN_BWD_FQC64 ? 64 : (variant == GSDD_ATTN_BWD_FQC128 ? 128 : 96);
+        const int nw = variant == GSDD_ATTN_BWD_NW8 ? 8 : 4;
         const int kb = 64 * nw, nkb = (L + kb - 1) / kb;
         const dim3 fgrid((unsigned)(B * H * nkb));
         if (dbgv == 1) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
@@ -828,11 +826,10 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
     }
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, q, o, dO, lse, im, B, L, H, dqkv);
     GSDD_CHECK_LAUNCH();
-    static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
-    if (first_on_device(attr_done)) {
+    GSDD_ONCE_PER_DEVICE(attr_done,
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sizeof(DkvSmem)));
-    }
+    );
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), sizeof(DkvSmem), st, k, v, im, B, L, H, dqkv);
     GSDD_CHECK_LAUNCH();
     *done = 1;

@@ -607,7 +607,7 @@ extern "C" int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out
 }
 
 int gsdd_attention_v4_with_lse(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
-                               void* workspace, int64_t workspace_bytes, void* stream, int* done);      // d3pm_attention.hip
+                               void* workspace, int64_t workspace_bytes, int mode, void* stream, int* done);      // d3pm_attention.hip
 
 // any sequence length (one lane per query, keys broadcast from LDS): the sampler's fallback for L % 16 != 0
 int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse, void* stream) {
@@ -618,10 +618,10 @@ int gsdd_attention_valu(const float* q, const float* k, const float* v, int B, i
 }
 
 extern "C" int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out,
-                                         float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+                                         float* lse, void* workspace, int64_t workspace_bytes, int mode, void* stream) {
     GSDD_CHECK_ARG(q && k && v && out && lse && B > 0 && L > 0 && H > 0, "bad args");
     int done = 0;
-    const int rc = gsdd_attention_v4_with_lse(q, k, v, B, L, H, out, lse, workspace, workspace_bytes, stream, &done);
+    const int rc = gsdd_attention_v4_with_lse(q, k, v, B, L, H, out, lse, workspace, workspace_bytes, mode, stream, &done);
     if (rc != GSDD_OK || done) return rc;
     hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((L + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, q, k, v, B, L, H,
                        out, lse);
@@ -630,17 +630,18 @@ extern "C" int gsdd_d3pm_attention_train(const float* q, const float* k, const f
 }
 
 int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse, int B,
-                            int L, int H, float* dqkv, void* workspace, int64_t workspace_bytes, void* stream,
+                            int L, int H, float* dqkv, void* workspace, int64_t workspace_bytes, int variant, void* stream,
                             int* done);                                                      // d3pm_attention_bwd.hip
 
 extern "C" int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO,
                                        const float* lse, int B, int L, int H, float* dqkv, float* scratch, void* workspace,
-                                       int64_t workspace_bytes, void* stream) {
+                                       int64_t workspace_bytes, int variant, void* stream) {
     GSDD_CHECK_ARG(q && k && v && o && dO && lse && dqkv && B > 0 && L > 0 && H > 0, "bad args");
-    const bool force_valu = getenv("GSDD_ATTN_BWD_VALU") != nullptr;            // A/B switch (read per call)
+    GSDD_CHECK_ARG(variant >= GSDD_ATTN_BWD_AUTO && variant <= GSDD_ATTN_BWD_DEV_LAST, "variant: one of GSDD_ATTN_BWD_*");
+    const bool force_valu = variant == GSDD_ATTN_BWD_VALU;
     if (!force_valu) {
         int done = 0;
-        const int rc = gsdd_attention_bwd_mfma(q, k, v, o, dO, lse, B, L, H, dqkv, workspace, workspace_bytes, stream, &done);
+        const int rc = gsdd_attention_bwd_mfma(q, k, v, o, dO, lse, B, L, H, dqkv, workspace, workspace_bytes, variant, stream, &done);
         if (rc != GSDD_OK || done) return rc;
     }
     GSDD_CHECK_ARG(scratch != nullptr, "the VALU backward needs the float[H*M] scratch");

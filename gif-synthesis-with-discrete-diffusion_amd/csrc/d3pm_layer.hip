@@ -22,7 +22,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int D = 64;          // n_embd
 constexpr int HID = 256;       // mlp hidden
 constexpr int W1P = 68;        // LDS pitch of W1 rows (k = 64): == 4 (mod 64) -> conflict-free ds_read_b128
-constexpr int W2P = 260;       // LDS pitch of W2 rows (k = 256)
 
 struct LayerArgs {
     const float* y;            // [M][64] attention output
@@ -72,31 +71,9 @@ __device__ __forceinline__ void load_frag(const float* row, int h, float (&r)[32
         }
 }
 
-// acc[nt] (features 32nt..32nt+31 of the output) += W[n][k] * act[k], k over the 64 features held in `act`;
-// W rows start at `w` with pitch `pitch` floats, column offset k0
-template <bool LDS_W>
-__device__ __forceinline__ void gemm64(const float* w, int pitch, int k0, int li, int h, const float (&act)[32],
-                                       f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 a0 = *reinterpret_cast<const float4*>(w + (int64_t)li * pitch + k0 + 32 * t + 8 * g + 4 * h);
-            float4 a1 = *reinterpret_cast<const float4*>(w + (int64_t)(32 + li) * pitch + k0 + 32 * t + 8 * g + 4 * h);
-            const int r = 16 * t + 4 * g;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, act[r + 0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, act[r + 0], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, act[r + 1], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, act[r + 1], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, act[r + 2], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, act[r + 2], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, act[r + 3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, act[r + 3], acc[1], 0, 0, 0);
-        }
-}
-
-// Same contraction with the MFMA operands swapped: acc[nt][r] = out[row (r&3)+8(r>>2)+4h][feature 32nt + li] — the feature is
-// on the lane, so a store instruction writes 2 x 128 contiguous bytes (used where the result goes straight to HBM).
+// acc[nt] += act (32 rows x 64 features in registers) x W[32 nt + li][k]^T on the exact-f32 matrix instruction, W rows at `w` with pitch
+// `pitch` floats: acc[nt][r] = out[row (r&3)+8(r>>2)+4h][feature 32nt + li] — the feature is on the lane, so a store instruction writes
+// 2 x 128 contiguous bytes (to_logits, whose result goes straight to HBM).
 __device__ __forceinline__ void gemm64_rows(const float* w, int pitch, int li, int h, const float (&act)[32], f32x16 (&acc)[2]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -135,226 +112,9 @@ __device__ __forceinline__ void row_norm(const float (&v)[32], float& mean, floa
     rstd = 1.0f / sqrtf(q * (1.f / 64.f) + 1e-5f);
 }
 
-// 64 x 64 weight block streamed from global memory (L2-resident): all 16 fragments are requested before the first MFMA, so the
-// GEMM pays one L2 round trip instead of one per k-group.
-__device__ __forceinline__ void gemm64_global(const float* w, int li, int h, const float (&act)[32], f32x16 (&acc)[2]) {
-    float4 a0[8], a1[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        a0[q] = *reinterpret_cast<const float4*>(w + (int64_t)li * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-        a1[q] = *reinterpret_cast<const float4*>(w + (int64_t)(32 + li) * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = 16 * (q >> 2) + 4 * (q & 3);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, act[r + 0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, act[r + 0], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, act[r + 1], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, act[r + 1], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, act[r + 2], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].z, act[r + 2], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].w, act[r + 3], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, act[r + 3], acc[1], 0, 0, 0);
-    }
-}
-
-// LDS map (floats): W1 [256][68] | W2 [64][260] | Wproj [64][68] | parameters (704) | per-wave scratch 8 x 192
-constexpr int LDS_W2 = HID * W1P, LDS_WP = LDS_W2 + D * W2P, LDS_PAR = LDS_WP + D * W1P;
+// parameter block of the fused layer kernels (floats)
 constexpr int PAR_BPROJ = 0, PAR_G2 = 64, PAR_B2LN = 128, PAR_B1 = 192, PAR_B2 = 448, PAR_BQKV = 512, PAR_N = 704;
-constexpr int LDS_SCR = LDS_PAR + PAR_N, LDS_LAYER_FLOATS = LDS_SCR + 8 * 192;
 
-template <bool HAS_QKV>
-__global__ __launch_bounds__(512, 1) void d3pm_layer_kernel(const LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sw1 = lds;                    // [256][68]
-    float* sw2 = lds + LDS_W2;           // [64][260]
-    float* swp = lds + LDS_WP;           // [64][68]
-    float* par = lds + LDS_PAR;          // biases and LayerNorm affine: LDS latency instead of an L2 round trip at every use
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, h = lane >> 5;
-    float* scr = lds + LDS_SCR + wave * 192;   // this wave's per-batch vectors: cvec | 1+scale | shift of the group's batch element
-
-    for (int i = tid; i < HID * (D / 4); i += 512) {             // W1 [256][64]
-        const int n = i >> 4, c = (i & 15) * 4;
-        *reinterpret_cast<float4*>(&sw1[n * W1P + c]) = *reinterpret_cast<const float4*>(a.w1 + n * D + c);
-    }
-    for (int i = tid; i < D * (HID / 4); i += 512) {             // W2 [64][256]
-        const int n = i >> 6, c = (i & 63) * 4;
-        *reinterpret_cast<float4*>(&sw2[n * W2P + c]) = *reinterpret_cast<const float4*>(a.w2 + n * HID + c);
-    }
-    for (int i = tid; i < D * (D / 4); i += 512) {               // Wproj [64][64]
-        const int n = i >> 4, c = (i & 15) * 4;
-        *reinterpret_cast<float4*>(&swp[n * W1P + c]) = *reinterpret_cast<const float4*>(a.wproj + n * D + c);
-    }
-    for (int i = tid; i < PAR_N; i += 512) {
-        float v;
-        if (i < PAR_G2) v = a.bproj[i];
-        else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2];
-        else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN];
-        else if (i < PAR_B2) v = a.b1[i - PAR_B1];
-        else if (i < PAR_BQKV) v = a.b2[i - PAR_B2];
-        else v = HAS_QKV ? a.bqkv[i - PAR_BQKV] : 0.f;
-        par[i] = v;
-    }
-    __syncthreads();
-
-    const int64_t ngroups = (a.M + 31) / 32;
-    const bool batch_uniform = a.L % 32 == 0;              // every 32-row group lies inside one batch element
-    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
-        const int64_t m = grp * 32 + li;
-        const bool valid = m < a.M;
-        const bool full = grp * 32 + 32 <= a.M;            // wave-uniform: all 32 rows exist -> unconditional stores
-        const int64_t mc = valid ? m : a.M - 1;
-        const int b = (int)((uint32_t)mc / (uint32_t)a.L);
-
-        // per-batch vectors of this group -> the wave's LDS scratch (same wave writes and reads: program order suffices)
-        if (batch_uniform) {
-            const int bu = (int)((uint32_t)(grp * 32) / (uint32_t)a.L);
-            if (lane < 16) {
-                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)bu * D + 4 * lane);
-                *reinterpret_cast<float4*>(scr + 4 * lane) = cv;
-            } else if (HAS_QKV && lane < 48) {
-                const float* tab = a.ada + a.t2[bu] * (2 * D);
-                *reinterpret_cast<float4*>(scr + 4 * lane) = *reinterpret_cast<const float4*>(tab + 4 * (lane - 16));
-            }
-        }
-
-        float act[32], x1[32];
-        f32x16 acc[2];
-        // ---- x1 = x + proj(y) + b_proj + cvec[b]
-        load_frag(a.y + mc * D, h, act);
-        load_frag(a.x + mc * D, h, x1);
-        zero2(acc);
-        gemm64<true>(swp, W1P, 0, li, h, act, acc);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 bp = *reinterpret_cast<const float4*>(par + PAR_BPROJ + f);
-                float4 cv;
-                if (batch_uniform) cv = *reinterpret_cast<const float4*>(scr + f);
-                else cv = a.cvec != nullptr ? *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int r = 4 * g;
-                x1[16 * t + r + 0] += (acc[t][r + 0] + bp.x) + cv.x;
-                x1[16 * t + r + 1] += (acc[t][r + 1] + bp.y) + cv.y;
-                x1[16 * t + r + 2] += (acc[t][r + 2] + bp.z) + cv.z;
-                x1[16 * t + r + 3] += (acc[t][r + 3] + bp.w) + cv.w;
-            }
-        // ---- h = LN2(x1) * gamma + beta
-        float mean, rstd;
-        row_norm(x1, mean, rstd);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 gm = *reinterpret_cast<const float4*>(par + PAR_G2 + f);
-                const float4 bt = *reinterpret_cast<const float4*>(par + PAR_B2LN + f);
-                const int r = 16 * t + 4 * g;
-                act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
-                act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
-                act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
-                act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
-            }
-        // ---- MLP in 4 chunks of 64 hidden units; the GELU2 output feeds W2 straight from registers
-        f32x16 acc3[2];
-        zero2(acc3);
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            zero2(acc);
-            gemm64<true>(sw1 + c * 64 * W1P, W1P, 0, li, h, act, acc);
-            float u[32];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 8 * g + 4 * h);
-                    const int r = 4 * g;
-                    u[16 * t + r + 0] = gelu2(acc[t][r + 0] + bb.x);
-                    u[16 * t + r + 1] = gelu2(acc[t][r + 1] + bb.y);
-                    u[16 * t + r + 2] = gelu2(acc[t][r + 2] + bb.z);
-                    u[16 * t + r + 3] = gelu2(acc[t][r + 3] + bb.w);
-                }
-            gemm64<true>(sw2, W2P, 64 * c, li, h, u, acc3);
-        }
-        // ---- x2 = x1 + mlp + b2 -> x
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B2 + f);
-                const int r = 4 * g;
-                x1[16 * t + r + 0] += acc3[t][r + 0] + bb.x;
-                x1[16 * t + r + 1] += acc3[t][r + 1] + bb.y;
-                x1[16 * t + r + 2] += acc3[t][r + 2] + bb.z;
-                x1[16 * t + r + 3] += acc3[t][r + 3] + bb.w;
-            }
-        if (full) {                                        // (a store under a lane mask makes the compiler wait for the previous one)
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
-                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
-        } else if (valid) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
-                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
-        }
-        if (HAS_QKV) {
-            // ---- next block: AdaLN(x2, t) then q|k|v
-            row_norm(x1, mean, rstd);
-            const float* tab = a.ada + a.t2[b] * (2 * D);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = 32 * t + 8 * g + 4 * h;
-                    float4 gm, bt;
-                    if (batch_uniform) {
-                        gm = *reinterpret_cast<const float4*>(scr + 64 + f);
-                        bt = *reinterpret_cast<const float4*>(scr + 128 + f);
-                    } else {
-                        gm = *reinterpret_cast<const float4*>(tab + f);
-                        bt = *reinterpret_cast<const float4*>(tab + D + f);
-                    }
-                    const int r = 16 * t + 4 * g;
-                    act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
-                    act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
-                    act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
-                    act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
-                }
-#pragma unroll 1
-            for (int c = 0; c < 3; ++c) {
-                zero2(acc);
-                gemm64_global(a.wqkv + (int64_t)c * 64 * D, li, h, act, acc);
-                float4 o[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int t = q >> 2, r = 4 * (q & 3);
-                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
-                    o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
-                }
-                // 4 consecutive outputs = one head's 4 dims: head-major q|k|v rows
-                if (full) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
-                    }
-                } else if (valid) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
-                    }
-                }
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // The same fused layer with every GEMM on the bf16 matrix pipe: each f32 operand element is split error-free into three
@@ -400,227 +160,6 @@ __device__ __forceinline__ void split_act(const float (&act)[32], P3 (&b)[4]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act[8 * q + j];
         b[q] = split8(v);
-    }
-}
-// acc[nt] += W[32 nt + li][k0 + 32 t + 16 s + ...] * (k-step q = 2t + s of the activation), weights f32 in LDS or global memory
-__device__ __forceinline__ void step_x3(const float* w, int pitch, int k0, int q, int li, int h, const P3& b, f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const float* row = w + (int64_t)(32 * nt + li) * pitch + k0 + 16 * q + 4 * h;
-        const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
-        const float wv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        mma6(split8(wv), b, acc[nt]);
-    }
-}
-__device__ __forceinline__ void gemm64_x3(const float* w, int pitch, int k0, int li, int h, const P3 (&b)[4], f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) step_x3(w, pitch, k0, q, li, h, b[q], acc);
-}
-
-template <bool HAS_QKV>
-__global__ __launch_bounds__(512, 1) void d3pm_layer_x3_kernel(const LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sw1 = lds;                    // [256][68]
-    float* sw2 = lds + LDS_W2;           // [64][260]
-    float* swp = lds + LDS_WP;           // [64][68]
-    float* par = lds + LDS_PAR;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, h = lane >> 5;
-    float* scr = lds + LDS_SCR + wave * 192;
-
-    for (int i = tid; i < HID * (D / 4); i += 512) {
-        const int n = i >> 4, c = (i & 15) * 4;
-        *reinterpret_cast<float4*>(&sw1[n * W1P + c]) = *reinterpret_cast<const float4*>(a.w1 + n * D + c);
-    }
-    for (int i = tid; i < D * (HID / 4); i += 512) {
-        const int n = i >> 6, c = (i & 63) * 4;
-        *reinterpret_cast<float4*>(&sw2[n * W2P + c]) = *reinterpret_cast<const float4*>(a.w2 + n * HID + c);
-    }
-    for (int i = tid; i < D * (D / 4); i += 512) {
-        const int n = i >> 4, c = (i & 15) * 4;
-        *reinterpret_cast<float4*>(&swp[n * W1P + c]) = *reinterpret_cast<const float4*>(a.wproj + n * D + c);
-    }
-    for (int i = tid; i < PAR_N; i += 512) {
-        float v;
-        if (i < PAR_G2) v = a.bproj[i];
-        else if (i < PAR_B2LN) v = a.ln2_g[i - PAR_G2];
-        else if (i < PAR_B1) v = a.ln2_b[i - PAR_B2LN];
-        else if (i < PAR_B2) v = a.b1[i - PAR_B1];
-        else if (i < PAR_BQKV) v = a.b2[i - PAR_B2];
-        else v = HAS_QKV ? a.bqkv[i - PAR_BQKV] : 0.f;
-        par[i] = v;
-    }
-    __syncthreads();
-
-    const int64_t ngroups = (a.M + 31) / 32;
-    const bool batch_uniform = a.L % 32 == 0;
-    for (int64_t grp = (int64_t)blockIdx.x * 8 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 8) {
-        const int64_t m = grp * 32 + li;
-        const bool valid = m < a.M;
-        const bool full = grp * 32 + 32 <= a.M;
-        const int64_t mc = valid ? m : a.M - 1;
-        const int b = (int)((uint32_t)mc / (uint32_t)a.L);
-        if (batch_uniform) {
-            const int bu = (int)((uint32_t)(grp * 32) / (uint32_t)a.L);
-            if (lane < 16) {
-                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.cvec != nullptr) cv = *reinterpret_cast<const float4*>(a.cvec + (int64_t)bu * D + 4 * lane);
-                *reinterpret_cast<float4*>(scr + 4 * lane) = cv;
-            } else if (HAS_QKV && lane < 48) {
-                const float* tab = a.ada + a.t2[bu] * (2 * D);
-                *reinterpret_cast<float4*>(scr + 4 * lane) = *reinterpret_cast<const float4*>(tab + 4 * (lane - 16));
-            }
-        }
-
-        float act[32], x1[32];
-        f32x16 acc[2];
-        P3 bp[4];
-        // ---- x1 = x + proj(y) + b_proj + cvec[b]
-        load_frag(a.y + mc * D, h, act);
-        load_frag(a.x + mc * D, h, x1);
-        split_act(act, bp);
-        zero2(acc);
-        gemm64_x3(swp, W1P, 0, li, h, bp, acc);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 bpj = *reinterpret_cast<const float4*>(par + PAR_BPROJ + f);
-                float4 cv;
-                if (batch_uniform) cv = *reinterpret_cast<const float4*>(scr + f);
-                else cv = a.cvec != nullptr ? *reinterpret_cast<const float4*>(a.cvec + (int64_t)b * D + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int r = 4 * g;
-                x1[16 * t + r + 0] += (acc[t][r + 0] + bpj.x) + cv.x;
-                x1[16 * t + r + 1] += (acc[t][r + 1] + bpj.y) + cv.y;
-                x1[16 * t + r + 2] += (acc[t][r + 2] + bpj.z) + cv.z;
-                x1[16 * t + r + 3] += (acc[t][r + 3] + bpj.w) + cv.w;
-            }
-        // ---- h = LN2(x1) * gamma + beta
-        float mean, rstd;
-        row_norm(x1, mean, rstd);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 gm = *reinterpret_cast<const float4*>(par + PAR_G2 + f);
-                const float4 bt = *reinterpret_cast<const float4*>(par + PAR_B2LN + f);
-                const int r = 16 * t + 4 * g;
-                act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
-                act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
-                act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
-                act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
-            }
-        split_act(act, bp);
-        // ---- MLP in 4 chunks of 64 hidden units; each k-step of the W2 product takes its 8 GELU2 outputs straight from the
-        //      W1 accumulators, splits them and is done with them
-        f32x16 acc3[2];
-        zero2(acc3);
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            zero2(acc);
-            gemm64_x3(sw1 + c * 64 * W1P, W1P, 0, li, h, bp, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = q >> 1, s = q & 1;
-                const float4 b0 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s + 4 * h);
-                const float4 b1 = *reinterpret_cast<const float4*>(par + PAR_B1 + 64 * c + 32 * t + 16 * s + 8 + 4 * h);
-                const float u[8] = {gelu2(acc[t][8 * s + 0] + b0.x), gelu2(acc[t][8 * s + 1] + b0.y), gelu2(acc[t][8 * s + 2] + b0.z),
-                                    gelu2(acc[t][8 * s + 3] + b0.w), gelu2(acc[t][8 * s + 4] + b1.x), gelu2(acc[t][8 * s + 5] + b1.y),
-                                    gelu2(acc[t][8 * s + 6] + b1.z), gelu2(acc[t][8 * s + 7] + b1.w)};
-                step_x3(sw2, W2P, 64 * c, q, li, h, split8(u), acc3);
-            }
-        }
-        // ---- x2 = x1 + mlp + b2 -> x
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = 32 * t + 8 * g + 4 * h;
-                const float4 bb = *reinterpret_cast<const float4*>(par + PAR_B2 + f);
-                const int r = 4 * g;
-                x1[16 * t + r + 0] += acc3[t][r + 0] + bb.x;
-                x1[16 * t + r + 1] += acc3[t][r + 1] + bb.y;
-                x1[16 * t + r + 2] += acc3[t][r + 2] + bb.z;
-                x1[16 * t + r + 3] += acc3[t][r + 3] + bb.w;
-            }
-        if (full) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
-                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
-        } else if (valid) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                *reinterpret_cast<float4*>(a.x + m * D + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
-                    make_float4(x1[4 * q + 0], x1[4 * q + 1], x1[4 * q + 2], x1[4 * q + 3]);
-        }
-        if (HAS_QKV) {
-            row_norm(x1, mean, rstd);
-            const float* tab = a.ada + a.t2[b] * (2 * D);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = 32 * t + 8 * g + 4 * h;
-                    float4 gm, bt;
-                    if (batch_uniform) {
-                        gm = *reinterpret_cast<const float4*>(scr + 64 + f);
-                        bt = *reinterpret_cast<const float4*>(scr + 128 + f);
-                    } else {
-                        gm = *reinterpret_cast<const float4*>(tab + f);
-                        bt = *reinterpret_cast<const float4*>(tab + D + f);
-                    }
-                    const int r = 16 * t + 4 * g;
-                    act[r + 0] = (x1[r + 0] - mean) * rstd * gm.x + bt.x;
-                    act[r + 1] = (x1[r + 1] - mean) * rstd * gm.y + bt.y;
-                    act[r + 2] = (x1[r + 2] - mean) * rstd * gm.z + bt.z;
-                    act[r + 3] = (x1[r + 3] - mean) * rstd * gm.w + bt.w;
-                }
-            split_act(act, bp);
-#pragma unroll 1
-            for (int c = 0; c < 3; ++c) {
-                // all 16 weight fragments of the 64 x 64 block are requested before the first split (one L2 round trip)
-                const float* wq = a.wqkv + (int64_t)c * 64 * D;
-                float4 w0[8], w1[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w0[2 * q] = *reinterpret_cast<const float4*>(wq + (int64_t)li * D + 16 * q + 4 * h);
-                    w0[2 * q + 1] = *reinterpret_cast<const float4*>(wq + (int64_t)li * D + 16 * q + 8 + 4 * h);
-                    w1[2 * q] = *reinterpret_cast<const float4*>(wq + (int64_t)(32 + li) * D + 16 * q + 4 * h);
-                    w1[2 * q + 1] = *reinterpret_cast<const float4*>(wq + (int64_t)(32 + li) * D + 16 * q + 8 + 4 * h);
-                }
-                zero2(acc);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v0[8] = {w0[2 * q].x, w0[2 * q].y, w0[2 * q].z, w0[2 * q].w, w0[2 * q + 1].x, w0[2 * q + 1].y, w0[2 * q + 1].z, w0[2 * q + 1].w};
-                    const float v1[8] = {w1[2 * q].x, w1[2 * q].y, w1[2 * q].z, w1[2 * q].w, w1[2 * q + 1].x, w1[2 * q + 1].y, w1[2 * q + 1].z, w1[2 * q + 1].w};
-                    mma6(split8(v0), bp[q], acc[0]);
-                    mma6(split8(v1), bp[q], acc[1]);
-                }
-                float4 o[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int t = q >> 2, r = 4 * (q & 3);
-                    const float4 bb = *reinterpret_cast<const float4*>(par + PAR_BQKV + 64 * c + 32 * t + 8 * (q & 3) + 4 * h);
-                    o[q] = make_float4(acc[t][r + 0] + bb.x, acc[t][r + 1] + bb.y, acc[t][r + 2] + bb.z, acc[t][r + 3] + bb.w);
-                }
-                if (full) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
-                    }
-                } else if (valid) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int n = 64 * c + 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-                        *reinterpret_cast<float4*>(a.qkv + ((int64_t)(n >> 2) * a.M + m) * 4) = o[q];
-                    }
-                }
-            }
-        }
     }
 }
 
@@ -1660,69 +1199,46 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     a.w1 = d->w1; a.b1 = d->b1; a.w2 = d->w2; a.b2 = d->b2;
     a.ada = d->ada; a.t2 = d->t2; a.wqkv = d->wqkv; a.bqkv = d->bqkv; a.qkv = d->qkv;
     a.range_flag = d->range_flag;
-    const size_t lds = (size_t)LDS_LAYER_FLOATS * sizeof(float);
     const int64_t ngroups = (d->M + 31) / 32;
     const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
-    static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
-    if (first_on_device(attr_done)) {
-        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
     a.w2_x3 = reinterpret_cast<const uint4*>(d->w2_x3); a.wqkv_x3 = reinterpret_cast<const uint4*>(d->wqkv_x3);
     a.lay_h2 = reinterpret_cast<const uint4*>(d->layer_h2); a.wqkv_h2 = reinterpret_cast<const uint4*>(d->wqkv_h2);
-    // GSDD_LAYER=f32 | x3 | x3p | h2 forces a variant (A/B; read per call); default: the f16 hi + lo images when the caller packed
-    // them, else the bf16x3 images, else on-the-fly splits
-    const char* force = getenv("GSDD_LAYER");
+    // d->variant picks the kernel (include/gsdd.h): GSDD_LAYER_AUTO = the f16 hi + lo images when the caller packed them, else the
+    // bf16x3 images.  (The exact-f32 and split-on-the-fly kernels of rounds 1-2 are gone: nothing reached them but an A/B switch.)
     const bool have_x3 = (qkv_only || d->w2_x3 != nullptr) && (!has_qkv || d->wqkv_x3 != nullptr);
     const bool have_h2 = (qkv_only || d->layer_h2 != nullptr) && (!has_qkv || d->wqkv_h2 != nullptr);
-    int variant;                                               // 0 f32, 1 bf16x3 split on the fly, 2 bf16x3 images, 3 f16 hi + lo images
-    if (force == nullptr) variant = have_h2 ? 3 : (have_x3 ? 2 : 1);
-    else if (strcmp(force, "f32") == 0) variant = 0;
-    else if (strcmp(force, "h2") == 0) variant = 3;
-    else if (strcmp(force, "x3p") == 0) variant = 2;
-    else if (strcmp(force, "x3") == 0) variant = 1;
-    else GSDD_CHECK_ARG(false, "GSDD_LAYER must be one of f32, x3, x3p, h2");
-    if (qkv_only && variant < 2) variant = have_h2 ? 3 : 2;
-    GSDD_CHECK_ARG(variant != 3 || have_h2, "GSDD_LAYER=h2 needs the gsdd_d3pm_layer_pack_h2 images");
-    GSDD_CHECK_ARG(variant != 2 || have_x3, "the bf16x3 image kernel needs the gsdd_d3pm_layer_pack images");
+    GSDD_CHECK_ARG(d->variant == GSDD_LAYER_AUTO || d->variant == GSDD_LAYER_X3P || d->variant == GSDD_LAYER_H2, "variant: one of GSDD_LAYER_*");
+    const int variant = d->variant == GSDD_LAYER_AUTO ? (have_h2 ? GSDD_LAYER_H2 : GSDD_LAYER_X3P) : d->variant;
+    GSDD_CHECK_ARG(variant != GSDD_LAYER_H2 || have_h2, "the f16 hi + lo kernel needs the gsdd_d3pm_layer_pack_h2 images");
+    GSDD_CHECK_ARG(variant != GSDD_LAYER_X3P || have_x3, "the bf16x3 kernel needs the gsdd_d3pm_layer_pack images (or pass the f16 hi + lo ones)");
     a.kimg = a.vimg = nullptr;
     a.knorm = nullptr;
     a.ksum = nullptr;
     if (has_qkv && d->kv_img != nullptr) {
-        GSDD_CHECK_ARG(variant >= 2 && d->L % 32 == 0, "kv_img needs a packed-weight kernel (fragment images) and L % 32 == 0");
+        GSDD_CHECK_ARG(d->L % 32 == 0, "kv_img needs L % 32 == 0");
         a.kimg = reinterpret_cast<uint4*>(d->kv_img);
         a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
         a.knorm = kv_image_knorm(d->kv_img, d->M * 16);
         a.ksum = kv_image_ksum(d->kv_img, d->M * 16);
     }
     GSDD_CHECK_ARG(!qkv_only || has_qkv, "y = NULL (q|k|v stage only) needs qkv");
-    if (variant == 3) {
+    if (variant == GSDD_LAYER_H2) {
         const size_t ldsh = (size_t)H2_LDS_FLOATS * sizeof(float);
-        static unsigned long long attr_h = 0ull;      // one bit per device: the attribute is per device
-        if (first_on_device(attr_h)) {
+        GSDD_ONCE_PER_DEVICE(attr_h,
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_h2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
-        }
+        );
         if (qkv_only) hipLaunchKernelGGL((d3pm_layer_h2_kernel<true, true>), dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
         else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_h2_kernel<true>, dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(d3pm_layer_h2_kernel<false>, dim3(grid), dim3(512), ldsh, (hipStream_t)stream, a);
-    } else if (variant == 0) {
-        if (has_qkv) hipLaunchKernelGGL(d3pm_layer_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(d3pm_layer_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-    } else if (variant == 1) {
-        if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3_kernel<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(d3pm_layer_x3_kernel<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     } else {
         const size_t ldsp = (size_t)X3P_LDS_FLOATS * sizeof(float);
-        static unsigned long long attr_p = 0ull;      // one bit per device: the attribute is per device
-        if (first_on_device(attr_p)) {
+        GSDD_ONCE_PER_DEVICE(attr_p,
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_layer_x3p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-        }
+        );
         if (qkv_only) hipLaunchKernelGGL((d3pm_layer_x3p_kernel<true, true>), dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
         else if (has_qkv) hipLaunchKernelGGL(d3pm_layer_x3p_kernel<true>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(d3pm_layer_x3p_kernel<false>, dim3(grid), dim3(512), ldsp, (hipStream_t)stream, a);
@@ -1743,10 +1259,9 @@ extern "C" int gsdd_rows_linear_pack_many(const void* descs_dev, int n_desc, int
 template <int KC, int NB>
 static int rows_linear_launch(const RowsLinArgs& a, void* stream) {
     const size_t ldsb = (size_t)NB * KC * 8 * IMG_FRAG_U4 * 16 + (size_t)64 * NB * sizeof(float);
-    static unsigned long long attr = 0ull;      // one bit per device: the attribute is per device
-    if (first_on_device(attr)) {
+    GSDD_ONCE_PER_DEVICE(attr,
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)rows_linear_kernel<KC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-    }
+    );
     const int64_t ngroups = (a.M + 31) / 32;
     const unsigned grid = (unsigned)std::min<int64_t>((ngroups + 7) / 8, 256);
     hipLaunchKernelGGL((rows_linear_kernel<KC, NB>), dim3(grid), dim3(512), ldsb, (hipStream_t)stream, a);
@@ -1800,10 +1315,9 @@ extern "C" int gsdd_d3pm_logits(const float* x, int64_t M, int n_embd, const flo
     LogitsArgs a;
     a.x = x; a.M = M; a.K = K; a.g = ln_g; a.b = ln_b; a.w = w; a.bias = bias; a.out = out;
     const size_t lds = (size_t)2 * LCH * W1P * sizeof(float);
-    static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
-    if (first_on_device(attr_done)) {
+    GSDD_ONCE_PER_DEVICE(attr_done,
         GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    );
     const unsigned grid = (unsigned)std::min<int64_t>((M + 255) / 256, 256);
     hipLaunchKernelGGL(d3pm_logits_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     GSDD_CHECK_LAUNCH();

@@ -762,8 +762,8 @@ extern "C" int gsdd_d3pm_step(const gsdd_step_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int J = (d->K + 255) / 256;
     const bool dbg = d->post_dbg != nullptr || d->x0_dbg != nullptr;
-    static const int occ_env = [] { const char* e = getenv("GSDD_STEP_OCC"); return e ? atoi(e) : 0; }();
-    if (J > 8 && J <= 16 && d->K == 4096 && !dbg && occ_env != 3) {       // the production shape: no scratch (see the kernel's note)
+    GSDD_CHECK_ARG(d->occupancy == 0 || d->occupancy == 2 || d->occupancy == 3, "occupancy: 0 (auto), 2 or 3 waves per SIMD");
+    if (J > 8 && J <= 16 && d->K == 4096 && !dbg && d->occupancy != 3) {       // the production shape: no scratch (see the kernel's note)
         hipLaunchKernelGGL((d3pm_step_kernel<16, true, false, 2>), grid, block, 0, st, *d, sp);
         GSDD_CHECK_LAUNCH();
         return GSDD_OK;
@@ -909,10 +909,15 @@ static int train_bwd_launch(const gsdd_train_desc* d, float* dlogits, bool with_
         if (with_loss) hipLaunchKernelGGL((d3pm_train_bwd_kernel<JJ, true>), grid, block, (size_t)4096 * JJ, st, a, sp);      \
         else hipLaunchKernelGGL((d3pm_train_bwd_kernel<JJ, false>), grid, block, (size_t)4096 * JJ, st, a, sp);               \
     } while (0)
-    static unsigned long long attr_done = 0ull;     // J = 32 (K up to 8192) needs 128 KB of dynamic LDS: above the 64 KB default
-    if (first_on_device(attr_done)) {
-        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_train_bwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
-        GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_train_bwd_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+    if (J > 16) {                                  // J = 32 (4096 < K <= 8192) needs 128 KB of dynamic LDS: above the 64 KB default
+        int dev = 0, lds_max = 0;
+        GSDD_CHECK_HIP(hipGetDevice(&dev));
+        GSDD_CHECK_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        GSDD_CHECK_ARG(lds_max >= 4096 * 32, "K > 4096 needs 128 KB of LDS per workgroup (gfx950 has 160 KB)");
+        GSDD_ONCE_PER_DEVICE(attr_done,
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_train_bwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)d3pm_train_bwd_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        );
     }
     if (d->K == 4096) {                            // the workload's class count: every register slot holds a class
         if (with_loss) hipLaunchKernelGGL((d3pm_train_bwd_kernel<16, true, true>), grid, block, (size_t)4096 * 16, st, a, sp);

@@ -414,18 +414,18 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
     GSDD_CHECK_ARG((int64_t)d->ntaps * d->Cout * d->Cin < (1ll << 31), "more than 2^31 weight elements");
     hipStream_t st = (hipStream_t)stream;
     unsigned gx = (unsigned)((M + BM - 1) / BM);
-    // bf16x3 on the matrix pipe when the contraction is long enough to pay for the splits; GSDD_GEMM_F32=1 forces the f32 MFMA
-    static const bool force_f32 = getenv("GSDD_GEMM_F32") != nullptr;
+    // bf16x3 on the matrix pipe when the contraction is long enough to pay for the splits; flags & GSDD_GEMM_EXACT_F32: the f32 MFMA
+    GSDD_CHECK_ARG((d->flags & ~GSDD_GEMM_EXACT_F32) == 0, "unknown flags");
+    const bool force_f32 = (d->flags & GSDD_GEMM_EXACT_F32) != 0;
     const bool x3 = !force_f32 && (int64_t)d->ntaps * d->Cin >= 64;
     if (d->Cout > 64) {
         const dim3 grid(gx, (d->Cout + 127) / 128);
         const bool big = x3 && M >= 256 * 1024 / 2 && (int64_t)d->ntaps * d->Cin >= 1024;        // long contraction, many rows
         if (big) {
-            static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
-            if (first_on_device(attr_done)) {
+            GSDD_ONCE_PER_DEVICE(attr_done,
                 GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<128, true, 256, 512>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GemmSmemX3<128, 256>)));
-            }
+            );
             const dim3 grid2((unsigned)((M + 255) / 256), (d->Cout + 127) / 128);
             hipLaunchKernelGGL((gemm_kernel<128, true, 256, 512>), grid2, dim3(512), sizeof(GemmSmemX3<128, 256>), st, *d, M);
         } else if (x3) hipLaunchKernelGGL((gemm_kernel<128, true>), grid, dim3(256), sizeof(GemmSmemX3<128>), st, *d, M);
@@ -436,11 +436,10 @@ extern "C" int gsdd_gemm(const gsdd_gemm_desc* d, void* stream) {
         // the matrix-pipe time of the 128 x 64 one on padding columns
         const bool narrow = x3 && d->Cout <= 32 && M >= 256 * 1024 / 2 && (int64_t)d->ntaps * d->Cin >= 1024;
         if (narrow) {
-            static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
-            if (first_on_device(attr_done)) {
+            GSDD_ONCE_PER_DEVICE(attr_done,
                 GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<32, true, 256, 256>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GemmSmemX3<32, 256>)));
-            }
+            );
             const dim3 grid2((unsigned)((M + 255) / 256), 1);
             hipLaunchKernelGGL((gemm_kernel<32, true, 256, 256>), grid2, dim3(256), sizeof(GemmSmemX3<32, 256>), st, *d, M);
         } else if (x3) hipLaunchKernelGGL((gemm_kernel<64, true>), grid, dim3(256), sizeof(GemmSmemX3<64>), st, *d, M);

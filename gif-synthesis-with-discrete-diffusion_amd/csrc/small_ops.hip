@@ -519,15 +519,16 @@ extern "C" int gsdd_small_linear(const float* x, int R, int Cin, const float* w,
 }
 
 extern "C" int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W, int C, int n_head, float* out,
-                                    void* stream) {
+                                    int variant, void* stream) {
     GSDD_CHECK_ARG(qkv && out, "null pointer");
+    GSDD_CHECK_ARG(variant == GSDD_AXIAL_AUTO || variant == GSDD_AXIAL_VALU, "variant: GSDD_AXIAL_AUTO or GSDD_AXIAL_VALU");
     GSDD_CHECK_ARG(N > 0 && T > 0 && H > 0 && W > 0 && C > 0 && n_head > 0 && C % n_head == 0, "bad sizes");
     GSDD_CHECK_ARG(T <= 64 && H <= 64 && W <= 64, "axis length > 64 unsupported");
     const int d = C / n_head;
     hipStream_t st = (hipStream_t)stream;
     const int axes_len[3] = {W, H, T};
     const int64_t pos = (int64_t)N * T * H * W;
-    static const bool force_valu = getenv("GSDD_AXIAL_VALU") != nullptr;
+    const bool force_valu = variant == GSDD_AXIAL_VALU;
     for (int axis = 0; axis < 3; ++axis) {
         if (!force_valu && axial_attention_mfma_launch(qkv, N, T, H, W, C, n_head, axis, out, st)) {
             GSDD_CHECK_LAUNCH();
@@ -550,8 +551,7 @@ extern "C" int gsdd_nearest_code(const float* z, int64_t M, int E, const float* 
     GSDD_CHECK_ARG(z && cb && idx, "null pointer");
     GSDD_CHECK_ARG(M > 0 && K > 0 && E > 0 && E % 4 == 0 && E <= 256, "E must be a multiple of 4, <= 256");
     hipStream_t st = (hipStream_t)stream;
-    static const bool force_valu = getenv("GSDD_NEAREST_VALU") != nullptr;               // A/B switch
-    if (E == NCM_E && K % 32 == 0 && workspace != nullptr && !force_valu) {
+    if (E == NCM_E && K % 32 == 0 && workspace != nullptr) {          // (workspace == NULL: the caller asks for the vector kernel)
         GSDD_CHECK_ARG(workspace_bytes >= gsdd_nearest_code_workspace_bytes(K), "workspace too small");
         GSDD_CHECK_ARG(M < (1ll << 31) * 16, "too many rows");
         float* en = reinterpret_cast<float*>(workspace);

@@ -479,7 +479,8 @@ extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_
     GSDD_CHECK_ARG(M < (1ll << 31), "more than 2^31 rows");
     GSDD_CHECK_ARG((int64_t)d->N * d->Di * d->Hi * d->Wi < (1ll << 31), "more than 2^31 input rows");
     GSDD_CHECK_ARG(d->oD > 0 && d->oH > 0 && d->oW > 0 && (int64_t)d->N * d->oD * d->oH * d->oW < (1ll << 31), "bad output dims");
-    static const bool force_f32 = getenv("GSDD_GEMM_F32") != nullptr;
+    GSDD_CHECK_ARG((d->flags & ~GSDD_GEMM_EXACT_F32) == 0, "unknown flags");
+    const bool force_f32 = (d->flags & GSDD_GEMM_EXACT_F32) != 0;
     const bool big = !force_f32 && d->Cout >= 128 && d->Cin >= 128;           // 128 x 128 output tiles on 512 threads
     const int T = big ? 128 : 64;
     const int ntiles = (d->Cout + T - 1) / T, ctiles = (d->Cin + T - 1) / T;
@@ -496,11 +497,10 @@ extern "C" int gsdd_conv_wgrad(const gsdd_gemm_desc* d, const float* dY, int dy_
     if (force_f32) {
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), sizeof(CwSmem), (hipStream_t)stream, *d, dY, dy_pitch, dW, M, slabs, ctiles);
     } else if (big) {
-        static unsigned long long attr_done = 0ull;      // one bit per device: the attribute is per device
-        if (first_on_device(attr_done)) {
+        GSDD_ONCE_PER_DEVICE(attr_done,
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sizeof(CwSmemX3<128>)));
-        }
+        );
         hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(512), sizeof(CwSmemX3<128>), (hipStream_t)stream, *d, dY, dy_pitch, dW, M,
                            slabs, ctiles);
     } else {
@@ -551,14 +551,15 @@ extern "C" int gsdd_lincomb(const float* a, const float* b, const float* c, floa
 }
 
 extern "C" int gsdd_axial_attention_bwd(const float* qkv, const float* datt, int N, int T, int H, int W, int C, int n_head,
-                                        float* dqkv, void* stream) {
+                                        float* dqkv, int variant, void* stream) {
     GSDD_CHECK_ARG(qkv && datt && dqkv, "null pointer");
+    GSDD_CHECK_ARG(variant == GSDD_AXIAL_AUTO || variant == GSDD_AXIAL_VALU, "variant: GSDD_AXIAL_AUTO or GSDD_AXIAL_VALU");
     GSDD_CHECK_ARG(N > 0 && T > 0 && H > 0 && W > 0 && C > 0 && n_head > 0 && C % n_head == 0, "bad sizes");
     GSDD_CHECK_ARG(T <= 64 && H <= 64 && W <= 64, "axis length > 64 unsupported");
     const int d = C / n_head;
     const int axes_len[3] = {W, H, T};
     const int64_t pos = (int64_t)N * T * H * W;
-    static const bool force_valu = getenv("GSDD_AXIAL_VALU") != nullptr;
+    const bool force_valu = variant == GSDD_AXIAL_VALU;
     for (int axis = 0; axis < 3; ++axis) {
         if (!force_valu && axial_attention_bwd_mfma_launch(qkv, datt, N, T, H, W, C, n_head, axis, dqkv, (hipStream_t)stream)) {
             GSDD_CHECK_LAUNCH();

@@ -124,6 +124,11 @@ class Text2ImageTransformer(nn.Module):
         self.condition_dim, self.diffusion_step = condition_dim, diffusion_step
         self.apply(self._init_weights)
         self._packed, self._packed_key = None, None
+        # how the softmax probabilities enter P.V in the self-attention kernel (include/gsdd.h, GSDD_ATTN_*): None = the library's
+        # default (adaptive lo half for L >= 2048, f16 hi + lo below), or 'a8' | '22' | '11' | 'a12'.  '11' (f16 hi only everywhere) is
+        # the fastest and data-independent: within the 1e-4 logits contract on every pinned case, not within the kernel's own 2e-5 bar
+        # on peaked rows.  The environment variable GSDD_ATTN_P overrides None.
+        self.attention_mode = None
 
     @staticmethod
     def _init_weights(module):                       # transformer_utils.py:363-371
@@ -178,6 +183,8 @@ class Text2ImageTransformer(nn.Module):
         if not (self.n_embd == 64 and layers and layers[0]["w1"].shape[0] == 256):
             return
         want = os.environ.get("GSDD_LAYER", "h2")
+        if want not in ("h2", "x3p"):
+            raise GsddError(f"GSDD_LAYER={want!r}: the fused layer kernels are 'h2' (f16 hi + lo images) and 'x3p' (bf16x3 images)")
         if want == "h2" and "lay_h2" not in layers[0] and "w2_x3" not in layers[0]:
             # the f16 images hold 2^8 w: a weight of 255 or more would overflow them (checked once per weight set; such a model takes
             # the bf16x3 kernel, which has f32's range)
@@ -256,9 +263,10 @@ class Text2ImageTransformer(nn.Module):
             # The fused layer kernel writes k and v straight into the attention workspace as the matrix-pipe kernel's pre-split
             # images (no f32 k|v rows, no pre-split pass); block 0 runs its q|k|v stage alone on the embedding
             attn_ws = ws.get("attn")
-            img = (attn_ws is not None and L % 32 == 0 and os.environ.get("GSDD_LAYER", "h2") in ("h2", "x3p")
+            amode = ops.attn_mode(self.attention_mode)
+            img = (attn_ws is not None and L % 32 == 0
                    and all(("lay_h2" in l and "wqkv_h2" in l) or ("w2_x3" in l and "wqkv_x3" in l) for l in layers)
-                   and not os.environ.get("GSDD_ATTN_V3"))
+                   and amode != ops.abi.ATTN_F32PV)
             x0, q0 = (x[:M1], ws["qkv0"]) if share0 else (x, qkv)
             if img:
                 ops.d3pm_layer(None, x0, L, None, nxt=layers[0], t2=t2, qkv=q0, kv_img=attn_ws, range_flag=ws.get("range"), stream=stream)
@@ -270,18 +278,18 @@ class Text2ImageTransformer(nn.Module):
             for li, lay in enumerate(layers):
                 if li == 0 and share0:
                     if img:
-                        ops.d3pm_attention(q0[0:H], None, None, B, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
+                        ops.d3pm_attention(q0[0:H], None, None, B, L, H, y, ws=attn_ws, redo=ws.get("redo"), mode=amode, stream=stream)
                     else:
-                        ops.d3pm_attention(q0[0:H], q0[H:2 * H], q0[2 * H:3 * H], B, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
+                        ops.d3pm_attention(q0[0:H], q0[H:2 * H], q0[2 * H:3 * H], B, L, H, y, ws=attn_ws, redo=ws.get("redo"), mode=amode, stream=stream)
                     with torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else contextlib.nullcontext():
                         for r in range(1, rep):
                             y[r * M1:(r + 1) * M1].copy_(y[:M1])
                 else:
                     with _timed(ws, "attention", stream):      # bench.py: HIP events around the dominant kernel, in situ
                         if img:
-                            ops.d3pm_attention(qkv[0:H], None, None, B2, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
+                            ops.d3pm_attention(qkv[0:H], None, None, B2, L, H, y, ws=attn_ws, redo=ws.get("redo"), mode=amode, stream=stream)
                         else:
-                            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=attn_ws, redo=ws.get("redo"), stream=stream)
+                            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=attn_ws, redo=ws.get("redo"), mode=amode, stream=stream)
                 nxt = layers[li + 1] if li + 1 < len(layers) else None
                 with _timed(ws, "layer" if nxt is not None else None, stream):
                     ops.d3pm_layer(y, x, L, lay, cvec=condv[li], nxt=nxt, t2=t2, qkv=qkv, kv_img=attn_ws if img else None,
@@ -305,7 +313,8 @@ class Text2ImageTransformer(nn.Module):
             ops.linear(x, lay["wqkv"], qkv, bias=lay["bqkv"],
                        ln=(stats, lay["ada1"].view(-1), lay["ada1"].view(-1)[D:], t2, 2 * D),
                        rows_per_batch=L, out_mode=2, stream=stream)
-            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), redo=ws.get("redo"), stream=stream)
+            ops.d3pm_attention(qkv[0:H], qkv[H:2 * H], qkv[2 * H:3 * H], B2, L, H, y, ws=ws.get("attn"), redo=ws.get("redo"),
+                               mode=ops.attn_mode(self.attention_mode), stream=stream)
             if Te == 1:
                 ops.linear(y, lay["wproj"], x, bias=lay["bproj"], bvec=condv[li], rows_per_batch=L, residual=x,
                            stream=stream)

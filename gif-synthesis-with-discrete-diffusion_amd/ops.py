@@ -1,12 +1,78 @@
 """Tensor-level wrappers over the C ABI (include/gsdd.h).  torch is used only to own device memory
 and streams; every computation below is a HIP kernel in libgsdd.so."""
 import ctypes as C
+import os
 
 import torch
 
-from ._lib import GemmDesc, LayerDesc, StepDesc, TrainDesc, check, lib, ptr, stream_ptr
+from . import _lib as abi
+from ._lib import GemmDesc, GsddError, LayerDesc, StepDesc, TrainDesc, check, lib, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_GELU2 = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------- variant / precision selection
+# The C ABI takes the arithmetic mode / kernel variant as an argument of each call (include/gsdd.h); libgsdd.so reads no environment.
+# The debugging switches the tests and the A/B tools have always used are environment variables: they are translated HERE, per call, into
+# those arguments (an explicit keyword argument of the wrapper wins over the environment).
+_ATTN_MODES = {"auto": abi.ATTN_AUTO, "22": abi.ATTN_P22, "11": abi.ATTN_P11, "a8": abi.ATTN_A8, "a12": abi.ATTN_A12,
+               "f32pv": abi.ATTN_F32PV, "kc256": abi.ATTN_KC256}
+_LAYER_VARIANTS = {"auto": abi.LAYER_AUTO, "h2": abi.LAYER_H2, "x3p": abi.LAYER_X3P}
+_ATTN_BWD_VARIANTS = {"auto": abi.ATTN_BWD_AUTO, "valu": abi.ATTN_BWD_VALU, "split": abi.ATTN_BWD_SPLIT, "fqc64": abi.ATTN_BWD_FQC64,
+                      "fqc128": abi.ATTN_BWD_FQC128, "nw8": abi.ATTN_BWD_NW8, "dbg1": abi.ATTN_BWD_DBG1, "dbg2": abi.ATTN_BWD_DBG2}
+
+
+def _pick(table, value, what):
+    if isinstance(value, int):
+        return value
+    try:
+        return table[str(value).lower()]
+    except KeyError:
+        raise GsddError(f"{what}: {value!r} is not one of {sorted(table)}") from None
+
+
+def attn_mode(mode=None):
+    """GSDD_ATTN_P = 22 | 11 | a8 | a12 (the sampler's P format), GSDD_ATTN_V3=1 (exact-f32 P.V kernel), GSDD_ATTN_KC=256."""
+    if mode is not None:
+        return _pick(_ATTN_MODES, mode, "attention mode")
+    if os.environ.get("GSDD_ATTN_V3"):
+        return abi.ATTN_F32PV
+    if os.environ.get("GSDD_ATTN_KC") == "256":
+        return abi.ATTN_KC256
+    return _pick(_ATTN_MODES, os.environ.get("GSDD_ATTN_P", "auto"), "GSDD_ATTN_P")
+
+
+def attn_train_mode(mode=None):
+    """GSDD_ATTN_TRAIN_P = 22 | a8 (explicit values only; anything else is an error)."""
+    v = mode if mode is not None else os.environ.get("GSDD_ATTN_TRAIN_P", "auto")
+    m = _pick(_ATTN_MODES, v, "GSDD_ATTN_TRAIN_P")
+    if m not in (abi.ATTN_AUTO, abi.ATTN_P22, abi.ATTN_A8):
+        raise GsddError(f"GSDD_ATTN_TRAIN_P: {v!r} is not one of '22', 'a8'")
+    return m
+
+
+def attn_bwd_variant(variant=None):
+    """GSDD_ATTN_BWD = valu | split | fqc64 | fqc128 | nw8 | dbg1 | dbg2 (development variants of the attention backward)."""
+    return _pick(_ATTN_BWD_VARIANTS, variant if variant is not None else os.environ.get("GSDD_ATTN_BWD", "auto"), "GSDD_ATTN_BWD")
+
+
+def layer_variant(variant=None):
+    """GSDD_LAYER = h2 | x3p."""
+    return _pick(_LAYER_VARIANTS, variant if variant is not None else os.environ.get("GSDD_LAYER", "auto"), "GSDD_LAYER")
+
+
+def gemm_flags(exact_f32=None):
+    """GSDD_GEMM_F32=1: the exact-f32 MFMA instead of the bf16x3 matrix pipe."""
+    if exact_f32 is None:
+        exact_f32 = bool(os.environ.get("GSDD_GEMM_F32"))
+    return abi.GEMM_EXACT_F32 if exact_f32 else 0
+
+
+def axial_variant(valu=None):
+    """GSDD_AXIAL_VALU=1: the LDS / vector kernel for every axis."""
+    if valu is None:
+        valu = bool(os.environ.get("GSDD_AXIAL_VALU"))
+    return abi.AXIAL_VALU if valu else abi.AXIAL_AUTO
 
 
 def taps_tensor(taps, device):
@@ -17,7 +83,7 @@ def taps_tensor(taps, device):
 def gemm(inp, w, out, *, in_dims, out_grid, stride=(1, 1, 1), taps=None, ntaps=1, cin=None, in_pitch=None,
          gather=None, pro=None, ln=None, epi_scale=None, epi_shift=None, bvec=None, rows_per_batch=0, act=ACT_NONE,
          residual=None, out_dims=None, out_step=(1, 1, 1), out_off=(0, 0, 0), out_pitch=None, out_mode=0, cout=None,
-         stream=None, _desc_only=False):
+         exact_f32=None, stream=None, _desc_only=False):
     """out[orow(m)][n] = epi(sum_tap sum_c pro(in[src(m,tap)][c]) * w[tap][n][c]).
 
     in_dims = (N, Di, Hi, Wi); out_grid = (Do, Ho, Wo); w: [ntaps][Cout][Cin];
@@ -51,6 +117,7 @@ def gemm(inp, w, out, *, in_dims, out_grid, stride=(1, 1, 1), taps=None, ntaps=1
     d.ood, d.ooh, d.oow = out_off
     d.out_pitch = out_pitch if out_pitch is not None else d.Cout
     d.out_mode = out_mode
+    d.flags = gemm_flags(exact_f32)
     if _desc_only:
         return d
     check(lib().gsdd_gemm(C.byref(d), stream_ptr(stream)))
@@ -78,9 +145,9 @@ def ncdhw_to_rows(x, cpad, padw, out=None, stream=None):
     return out
 
 
-def axial_attention(qkv, dims, C_, n_head, out, stream=None):
+def axial_attention(qkv, dims, C_, n_head, out, valu=None, stream=None):
     N, T, H, W = dims
-    check(lib().gsdd_axial_attention(ptr(qkv), N, T, H, W, C_, n_head, ptr(out), stream_ptr(stream)))
+    check(lib().gsdd_axial_attention(ptr(qkv), N, T, H, W, C_, n_head, ptr(out), axial_variant(valu), stream_ptr(stream)))
     return out
 
 
@@ -98,7 +165,7 @@ def pool3d(x, dims, C_, kernel, stride, pad_front, out_grid, out, *, mode="max",
 def nearest_code(z, cb, idx, zq=None, stream=None, matrix=True):
     """matrix=False: no workspace -> the register-tiled vector kernel whatever the shape (tests compare the two)."""
     ws = None
-    if matrix:
+    if matrix and not os.environ.get("GSDD_NEAREST_VALU"):
         ws = torch.empty((lib().gsdd_nearest_code_workspace_bytes(cb.shape[0]) // 4,), dtype=torch.float32, device=z.device)
     check(lib().gsdd_nearest_code(ptr(z), z.shape[0], z.shape[1], ptr(cb), cb.shape[0], ptr(idx), ptr(zq), ptr(ws),
                                   0 if ws is None else ws.numel() * 4, stream_ptr(stream)))
@@ -181,15 +248,17 @@ def d3pm_attention_workspace(B, L, H, device):
     return torch.empty(((n + 3) // 4,), dtype=torch.float32, device=device)
 
 
-def d3pm_attention(q, k, v, B, L, H, out, ws=None, redo=None, stream=None):
+def d3pm_attention(q, k, v, B, L, H, out, ws=None, redo=None, mode=None, stream=None):
     """ws: scratch from d3pm_attention_workspace (matrix-pipe kernel); None -> workspace-free exact-f32 P.V kernel.
-    redo: optional int64[1] device counter of the kernel's chunk-redo events (caller-owned; see include/gsdd.h)."""
+    redo: optional int64[1] device counter of the kernel's chunk-redo events (caller-owned; see include/gsdd.h).
+    mode: 'auto' | '22' | '11' | 'a8' | 'a12' | 'f32pv' | 'kc256' (GSDD_ATTN_* of include/gsdd.h); None -> the environment, else auto."""
     nbytes = 0 if ws is None else ws.numel() * 4
-    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(ws), nbytes, ptr(redo), stream_ptr(stream)))
+    check(lib().gsdd_d3pm_attention(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(ws), nbytes, ptr(redo), attn_mode(mode),
+                                    stream_ptr(stream)))
     return out
 
 
-def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, range_flag=None, stream=None):
+def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None, range_flag=None, variant=None, stream=None):
     """Fused post-attention half of a block (+ the next block's AdaLN/qkv when `nxt` is given).
     y = lay = None: only the next-block stage on x as it is (block 0, whose input is the embedding)."""
     d = LayerDesc()
@@ -207,6 +276,7 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None
         d.wqkv_h2 = ptr(nxt.get("wqkv_h2"))
         d.kv_img = ptr(kv_img)
     d.range_flag = ptr(range_flag)
+    d.variant = layer_variant(variant)
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))
 
 
@@ -263,6 +333,7 @@ def d3pm_step(logits_c, logits_u, tok_in, tok_out, sched, t_dev, stream_dev, *, 
               post_dbg=None, x0_dbg=None, stream=None):
     B, L = tok_in.shape
     d = StepDesc()
+    d.occupancy = int(os.environ.get("GSDD_STEP_OCC", "0"))
     d.logits_c, d.logits_u = ptr(logits_c), ptr(logits_u)
     d.tok_in, d.tok_out = ptr(tok_in), ptr(tok_out)
     d.B, d.L, d.K, d.T = B, L, K, T
@@ -446,9 +517,9 @@ def batch_rowsum(Y, B, L, out=None, stream=None):
     return out
 
 
-def d3pm_attention_train(q, k, v, B, L, H, out, lse, ws=None, stream=None):
+def d3pm_attention_train(q, k, v, B, L, H, out, lse, ws=None, mode=None, stream=None):
     check(lib().gsdd_d3pm_attention_train(ptr(q), ptr(k), ptr(v), B, L, H, ptr(out), ptr(lse), ptr(ws),
-                                          0 if ws is None else ws.numel() * ws.element_size(), stream_ptr(stream)))
+                                          0 if ws is None else ws.numel() * ws.element_size(), attn_train_mode(mode), stream_ptr(stream)))
 
 
 def d3pm_attention_bwd_workspace(B, L, H, device):
@@ -456,11 +527,11 @@ def d3pm_attention_bwd_workspace(B, L, H, device):
     return torch.empty((n // 4,), dtype=torch.float32, device=device)
 
 
-def d3pm_attention_bwd(q, k, v, o, dO, lse, B, L, H, ws=None, stream=None):
+def d3pm_attention_bwd(q, k, v, o, dO, lse, B, L, H, ws=None, variant=None, stream=None):
     dqkv = torch.empty((B * L, 3 * H * 4), dtype=torch.float32, device=q.device)
     scratch = torch.empty((H * B * L,), dtype=torch.float32, device=q.device)
     check(lib().gsdd_d3pm_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), B, L, H, ptr(dqkv), ptr(scratch), ptr(ws),
-                                        0 if ws is None else ws.numel() * ws.element_size(), stream_ptr(stream)))
+                                        0 if ws is None else ws.numel() * ws.element_size(), attn_bwd_variant(variant), stream_ptr(stream)))
     return dqkv
 
 
@@ -516,8 +587,8 @@ def lincomb(a, b, c, alpha, stream=None):
     return out
 
 
-def axial_attention_bwd(qkv, datt, dims, C_, n_head, stream=None):
+def axial_attention_bwd(qkv, datt, dims, C_, n_head, valu=None, stream=None):
     N, T, H, W = dims
     dqkv = torch.empty_like(qkv)
-    check(lib().gsdd_axial_attention_bwd(ptr(qkv), ptr(datt), N, T, H, W, C_, n_head, ptr(dqkv), stream_ptr(stream)))
+    check(lib().gsdd_axial_attention_bwd(ptr(qkv), ptr(datt), N, T, H, W, C_, n_head, ptr(dqkv), axial_variant(valu), stream_ptr(stream)))
     return dqkv

@@ -13,6 +13,9 @@
  *   - fp32 everywhere; token / code indices are int64 (torch.argmin/argmax dtype).
  *   - return 0 on success, <0 on error (GSDD_E_*); gsdd_last_error() gives a message (thread-local).
  *   - activations are channels-last: a "row" is one position (n,t,h,w) with C contiguous floats.
+ *   - arithmetic mode / kernel variant are ARGUMENTS (a `mode` / `variant` / `flags` value, 0 = the documented default), chosen per
+ *     call and therefore per stream; the library reads no environment variable and keeps no mode latched in static state.  (The
+ *     Python shells map their GSDD_* debugging environment variables onto these arguments: gif-synthesis-with-discrete-diffusion_amd/ops.py.)
  */
 #ifndef GSDD_H
 #define GSDD_H
@@ -71,7 +74,12 @@ typedef struct {
     int oD, oH, oW, osd, osh, osw, ood, ooh, oow, out_pitch;
     int out_mode;                   /* 0 channels-last rows; 1 NCDHW (out[n][c][d][h][w]);
                                        2 head-major [n/4][M][4] (denoiser q/k/v)             */
+    int flags;                      /* 0, or GSDD_GEMM_EXACT_F32                             */
 } gsdd_gemm_desc;
+/* flags: contractions of 64 or more run as error-free 3-way bf16 splits on the matrix pipe by default (six cross products, dropped
+ * terms < 2^-24 relative); GSDD_GEMM_EXACT_F32 runs them on v_mfma_f32_32x32x2_f32 (an fmaf chain in f32) instead -- also honoured by
+ * gsdd_conv_wgrad. */
+#define GSDD_GEMM_EXACT_F32 1
 int gsdd_gemm(const gsdd_gemm_desc* d, void* stream);
 
 /* per-row LayerNorm statistics (mean, rstd) of x[M][C] (eps inside rsqrt).
@@ -87,8 +95,10 @@ int gsdd_ncdhw_to_rows(const float* x, int N, int C, int D, int H, int W, int Cp
  * Axial attention over one axis of a (N,T,H,W) grid of fused q|k|v rows.
  * qkv row layout: [9*C] = (axis a: q,k,v) for a in (w,h,t); out row layout [3*C] = (a_w|a_h|a_t).
  * Replaces AxialAttention + scaled_dot_product_attention: model_utils.py:318-337, :586-600. */
+#define GSDD_AXIAL_AUTO 0           /* register-resident MFMA kernel where the line length and head dim allow (16-position lines) */
+#define GSDD_AXIAL_VALU 1           /* the LDS / vector kernel for every axis (any line length <= 64): the cross-check variant    */
 int gsdd_axial_attention(const float* qkv, int N, int T, int H, int W, int C, int n_head,
-                         float* out, void* stream);
+                         float* out, int variant, void* stream);
 
 /* Nearest codebook entry: idx[m] = argmin_k (|z_m|^2 - 2 z_m.e_k + |e_k|^2), first minimum wins.
  * Replaces Codebook.forward distance+argmin: videogpt_vq_vae.py:178-183.
@@ -152,7 +162,7 @@ int gsdd_relu_mask(const float* dout, const float* out, float* dpre, int64_t n, 
 int gsdd_lincomb(const float* a, const float* b, const float* c, float alpha, float* out, int64_t n, void* stream);
 /* backward of gsdd_axial_attention: datt rows [M][3C] -> dqkv rows [M][9C] */
 int gsdd_axial_attention_bwd(const float* qkv, const float* datt, int N, int T, int H, int W, int C, int n_head, float* dqkv,
-                             void* stream);
+                             int variant /* GSDD_AXIAL_* */, void* stream);
 
 /* ------------------------------------------------------------------ D3PM denoiser pieces
  * x[b][l][:] = emb[tok[b][l]] + pos[l]   (DalleMaskImageEmbedding.forward, dalle_mask_image_embedding.py:59-79;
@@ -184,8 +194,25 @@ int64_t gsdd_d3pm_attention_workspace_bytes(int B, int L, int H);
  * redo_events: optional device counter (caller-owned, caller-zeroed) to which the kernel adds one per (wave, chunk) it had to
  * redo with a larger exponent offset after an f16 overflow -- the kernel's only other data-dependent cost, 0 for near-uniform
  * attention rows.  The library keeps no counter of its own (no hidden global state). */
+/* mode: how the softmax probabilities P enter the P.V product on the f16 matrix pipe (errors and times: DESIGN.md section 4).
+ *   GSDD_ATTN_AUTO   GSDD_ATTN_A8 for L >= 2048, GSDD_ATTN_P22 below (short rows have too few keys to average the skipped halves out)
+ *   GSDD_ATTN_P22    f16 hi + lo (22 bits) in every tile: the most exact variant (output within 2e-6 of fp64)
+ *   GSDD_ATTN_P11    f16 hi only (11 bits) in every tile: the fastest; relative error of a probability <= 2^-12, output error up to
+ *                    ~1.4e-4 |v - o| / sqrt(effective keys per row) -- within the path's 1e-4 logits contract on every pinned case
+ *                    (tests/test_gpu_parity.py, tests/test_gpu_fullsize.py), but not within this kernel's own 2e-5 bar on peaked rows
+ *   GSDD_ATTN_A8     adaptive: lo half only in (16-query, 32-key) tiles that can hold a probability above 2^-8 of the row sum
+ *   GSDD_ATTN_A12    the same with threshold 2^-12
+ *   GSDD_ATTN_F32PV  the workspace-free kernel (exact-f32 P.V) even when a workspace is given (k, v must be given)
+ *   GSDD_ATTN_KC256  development variant: 256-key chunks, hi + lo everywhere */
+#define GSDD_ATTN_AUTO 0
+#define GSDD_ATTN_P22 1
+#define GSDD_ATTN_P11 2
+#define GSDD_ATTN_A8 3
+#define GSDD_ATTN_A12 4
+#define GSDD_ATTN_F32PV 5
+#define GSDD_ATTN_KC256 6
 int gsdd_d3pm_attention(const float* q, const float* k, const float* v, int B, int L, int H,
-                        float* out, void* workspace, int64_t workspace_bytes, uint64_t* redo_events, void* stream);
+                        float* out, void* workspace, int64_t workspace_bytes, uint64_t* redo_events, int mode, void* stream);
 
 /* Fused post-attention half of a denoiser block (n_embd 64, hidden 256), rows updated in place:
  *   x += proj(y)+b_proj+cvec[b];  x += W2 GELU2(W1 LN2(x)+b1)+b2;  [qkv_next = Wqkv AdaLN_next(x,t)+b_qkv, head-major]
@@ -207,21 +234,26 @@ typedef struct {
     const int64_t* t2;          /* device int64[M/L] timesteps                      */
     const float* wqkv; const float* bqkv; /* [192][64], [192]                       */
     float* qkv;                 /* [48][M][4] or NULL                               */
-    const void* w2_x3;          /* optional: gsdd_d3pm_layer_pack images (bf16x3 MFMA fragments) of this block's w2 + wproj */
-    const void* wqkv_x3;        /* and of the next block's wqkv.  With them the kernel streams ready-made matrix operands    */
-                                /* through LDS instead of splitting the f32 weights once per 32-row group                    */
-    void* kv_img;               /* optional (needs both images above and L % 32 == 0): the attention workspace of the next     */
+    const void* w2_x3;          /* gsdd_d3pm_layer_pack images (bf16x3 MFMA fragments) of this block's w2 + wproj and of the */
+    const void* wqkv_x3;        /* next block's wqkv: ready-made matrix operands streamed through LDS.  One of the two image */
+                                /* sets (these or layer_h2 / wqkv_h2) must be given                                           */
+    void* kv_img;               /* optional (L % 32 == 0): the attention workspace of the next                                  */
                                 /* block.  k and v are then written there as the matrix-pipe kernel's pre-split images instead */
                                 /* of f32 rows of qkv, and gsdd_d3pm_attention is called with k = v = NULL (no prep pass)      */
     const void* layer_h2;       /* optional: gsdd_d3pm_layer_pack_h2 images (f16 hi + lo MFMA fragments) of this block's w1, w2 and */
     const void* wqkv_h2;        /* wproj, and of the next block's wqkv.  Preferred over the bf16x3 images when given: all three    */
                                 /* weight matrices of the block are then LDS-resident and every product is 3 matrix instructions   */
                                 /* instead of 6; as accurate as an f32 GEMM with f32 accumulation (22-bit operands, exact products) */
+    int variant;                /* GSDD_LAYER_AUTO (the f16 hi + lo kernel when its images are given, else the bf16x3 one), or one of */
+                                /* them explicitly: GSDD_LAYER_H2 / GSDD_LAYER_X3P (an error if that kernel's images are missing)    */
     int* range_flag;            /* optional device int (caller-zeroed), used by the f16 hi + lo kernel only: its operands are 16 a as  */
                                 /* f16, so an activation |a| >= 4094 overflows to inf.  The kernel sets *range_flag = 1 when a row of  */
                                 /* x it writes is not finite (inf / NaN propagate there); the caller then reruns with the bf16x3       */
                                 /* images, which have f32's range (d3pm.py does: checked once per sample(), outside graph capture)    */
 } gsdd_layer_desc;
+#define GSDD_LAYER_AUTO 0
+#define GSDD_LAYER_X3P 2
+#define GSDD_LAYER_H2 3
 int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream);
 /* Pre-split w2 [64][256] + wproj [64][64] (-> layer_x3, GSDD_LAYER_X3_BYTES) and wqkv [192][64] (-> wqkv_x3,
  * GSDD_LAYER_WQKV_X3_BYTES; both may be NULL) into the fragment images gsdd_d3pm_layer consumes; valid until the weights change. */
@@ -281,6 +313,8 @@ typedef struct {
     int64_t row0;               /* global row offset of this shard (multi-GPU batch split)   */
     float* post_dbg;
     float* x0_dbg;
+    int occupancy;              /* 0 = default; 2 / 3: waves per SIMD the K = 4096 kernel's register budget is sized for       */
+                                /* (development switch: the default is 2, no scratch)                                          */
 } gsdd_step_desc;
 int gsdd_d3pm_step(const gsdd_step_desc* d, void* stream);
 
@@ -339,14 +373,28 @@ int gsdd_batch_rowsum(const float* Y, int B, int L, int C, float* out, void* str
 /* head-dim-4 self-attention for training: forward that also returns the log2-domain log-sum-exp per (head,row), and the
  * backward (dq|dk|dv rows [M][3*H*4]); scratch: float[H*M].  With a workspace of gsdd_d3pm_attention_workspace_bytes() and
  * L % 32 == 0 the forward runs on the matrix-pipe kernel of gsdd_d3pm_attention; workspace may be NULL (VALU kernel). */
+/* mode: GSDD_ATTN_AUTO (= GSDD_ATTN_A8 for L >= 2048, else GSDD_ATTN_P22), GSDD_ATTN_P22 or GSDD_ATTN_A8; anything else is an error. */
 int gsdd_d3pm_attention_train(const float* q, const float* k, const float* v, int B, int L, int H, float* out, float* lse,
-                              void* workspace, int64_t workspace_bytes, void* stream);
+                              void* workspace, int64_t workspace_bytes, int mode, void* stream);
 /* With a workspace of gsdd_d3pm_attention_bwd_workspace_bytes() and L % 32 == 0 the backward runs on the bf16 matrix pipe
  * (pre-split operand images, dQ kernel + dK/dV kernel); otherwise on the VALU kernels, which need `scratch`. */
 int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H);
+/* variant: GSDD_ATTN_BWD_AUTO = the fused kernel (one pass over the scores for dQ, dK and dV); GSDD_ATTN_BWD_VALU = the vector
+ * kernels whatever the shape; the rest are development variants kept as cross-checks of each other (tests/test_gpu_training.py):
+ * _SPLIT = dQ kernel + dK/dV kernel, _FQC64 / _FQC128 = queries per LDS chunk of the fused kernel (default 96), _NW8 = eight waves
+ * per workgroup, _DBG1 / _DBG2 = the fused kernel stopping after its dQ / dK stage. */
+#define GSDD_ATTN_BWD_AUTO 0
+#define GSDD_ATTN_BWD_VALU 1
+#define GSDD_ATTN_BWD_SPLIT 2
+#define GSDD_ATTN_BWD_FQC64 3
+#define GSDD_ATTN_BWD_FQC128 4
+#define GSDD_ATTN_BWD_NW8 5
+#define GSDD_ATTN_BWD_DBG1 6
+#define GSDD_ATTN_BWD_DBG2 7
+#define GSDD_ATTN_BWD_DEV_LAST 7
 int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
                             int B, int L, int H, float* dqkv, float* scratch, void* workspace, int64_t workspace_bytes,
-                            void* stream);
+                            int variant, void* stream);
 /* demb[tok] += dx, dpos[l] += dx */
 int gsdd_d3pm_embed_bwd(const float* dx, const int64_t* tok, int B, int L, int D, int n_embed, float* demb, float* dpos,
                         void* stream);

@@ -573,7 +573,7 @@ def test_near_tie_stress_vectors(G, golden):
 
 def test_fused_layer_variants_agree(G, monkeypatch):
     """gsdd_d3pm_layer with the f16 hi + lo weight images (default when Text2ImageTransformer packs them), with the bf16x3 images
-    (GSDD_LAYER=x3p), without images (weights split on the fly), and writing k/v as attention images instead of f32 rows: same
+    (variant 'x3p'), and writing k/v as attention images instead of f32 rows: same
     block output, each also against an fp64 evaluation of the block; the image path is checked through the attention kernel that
     consumes it."""
     torch.manual_seed(11)
@@ -585,7 +585,6 @@ def test_fused_layer_variants_agree(G, monkeypatch):
         for p_ in tr.parameters():
             p_.mul_(8.0)                      # N(0, 0.02) init would make every block nearly the identity
     lay0, lay1 = (dict(l) for l in tr.packed()["layers"])
-    plain0, plain1 = dict(lay0), dict(lay1)
     x3_0, x3_1 = dict(lay0), dict(lay1)
     for lay in (lay0, lay1):                  # the sampler makes these on first use
         lay["lay_h2"], lay["wqkv_h2"] = G.ops.d3pm_layer_pack_h2(lay["w1"], lay["w2"], lay["wproj"], lay["wqkv"])
@@ -606,7 +605,7 @@ def test_fused_layer_variants_agree(G, monkeypatch):
     an = torch.nn.functional.layer_norm(x2, (Dm,), None, None, 1e-5) * tab[:, :Dm] + tab[:, Dm:]
     qkv64 = (an @ f("wqkv", lay1).T + f("bqkv", lay1)).reshape(M, 3 * H, 4).permute(1, 0, 2)
     outs, errs = [], {}
-    for name, l0, l1 in (("h2", lay0, lay1), ("x3p", x3_0, x3_1), ("x3", plain0, plain1)):
+    for name, l0, l1 in (("h2", lay0, lay1), ("x3p", x3_0, x3_1)):
         x = x_in.clone()
         qkv = torch.zeros(3 * H, M, 4, device="cuda")
         G.ops.d3pm_layer(y, x, L, l0, cvec=cv, nxt=l1, t2=t2, qkv=qkv)
@@ -621,13 +620,11 @@ def test_fused_layer_variants_agree(G, monkeypatch):
         torch.testing.assert_close(outs[0][0], o[0], atol=4e-5, rtol=1e-6)
         torch.testing.assert_close(outs[0][1], o[1], atol=2e-5, rtol=0)
     # k, v as images: attention on (q rows, images) == attention on the f32 q, k, v rows -- for both image kernels
-    for (l0, l1), ref, env in (((lay0, lay1), outs[0], None), ((x3_0, x3_1), outs[1], "x3p")):
-        if env:
-            monkeypatch.setenv("GSDD_LAYER", env)
+    for (l0, l1), ref, variant in (((lay0, lay1), outs[0], None), ((x3_0, x3_1), outs[1], "x3p")):
         ws = G.ops.d3pm_attention_workspace(B2, L, H, torch.device("cuda"))
         x = x_in.clone()
         qkv2 = torch.zeros(3 * H, M, 4, device="cuda")
-        G.ops.d3pm_layer(y, x, L, l0, cvec=cv, nxt=l1, t2=t2, qkv=qkv2, kv_img=ws)
+        G.ops.d3pm_layer(y, x, L, l0, cvec=cv, nxt=l1, t2=t2, qkv=qkv2, kv_img=ws, variant=variant)
         torch.testing.assert_close(x, ref[0], atol=0, rtol=0)
         assert torch.equal(qkv2[:H], ref[1][:H]) and not qkv2[H:].any()          # q rows written, k/v rows untouched
         a_img = torch.empty(M, Dm, device="cuda")
@@ -648,7 +645,6 @@ def test_fused_layer_variants_agree(G, monkeypatch):
         ks_img, ks_ref = ws[o_sum:o_sum + 4 * ntile].view(ntile, 4), ws_ref[o_sum:o_sum + 4 * ntile].view(ntile, 4)
         torch.testing.assert_close(ks_img, ks_ref, atol=2e-5, rtol=1e-5)           # (k itself differs in the last bits between the layer variants)
         torch.testing.assert_close(ks_ref.double(), k.double().view(ntile, 32, 4).sum(dim=1), atol=1e-4, rtol=1e-5)
-        monkeypatch.delenv("GSDD_LAYER", raising=False)
 
 
 def test_layer_kernel_range_screen_falls_back_to_bf16x3(G, golden, monkeypatch):
@@ -710,7 +706,9 @@ def test_denoiser_ragged_lengths_match_oracle(G, L, spatial):
 
 
 def test_layer_kernel_variant_without_its_images_fails_loudly(G, monkeypatch):
-    """Forcing an image kernel (GSDD_LAYER=h2 / x3p) on a call that carries no images of that kind is an error, not a silent switch."""
+    """Asking for an image kernel (variant 'h2' / 'x3p', or GSDD_LAYER in the environment) on a call that carries no images of that
+    kind is an error, not a silent switch; so is a call with no images at all (the split-on-the-fly kernels are gone), and an unknown
+    variant name never reaches the library."""
     torch.manual_seed(3)
     d = G.DalleMaskImageEmbedding(num_embed=33, spatial_size=[8, 8], embed_dim=64)
     tr = G.Text2ImageTransformer(dalle=d, n_layer=1, n_embd=64, n_head=16, content_seq_len=64, block_activate="GELU2",
@@ -719,11 +717,21 @@ def test_layer_kernel_variant_without_its_images_fails_loudly(G, monkeypatch):
     x = torch.randn(64, 64, device="cuda")
     y = torch.randn(64, 64, device="cuda")
     for forced in ("h2", "x3p"):
+        with pytest.raises(G.GsddError):
+            G.ops.d3pm_layer(y, x.clone(), 64, lay, variant=forced)
         monkeypatch.setenv("GSDD_LAYER", forced)
         with pytest.raises(G.GsddError):
             G.ops.d3pm_layer(y, x.clone(), 64, lay)
-    monkeypatch.delenv("GSDD_LAYER")
-    G.ops.d3pm_layer(y, x.clone(), 64, lay)       # no images, no forcing: the split-on-the-fly kernel
+        monkeypatch.delenv("GSDD_LAYER")
+    with pytest.raises(G.GsddError):
+        G.ops.d3pm_layer(y, x.clone(), 64, lay)   # no images at all
+    with pytest.raises(G.GsddError):
+        G.ops.d3pm_layer(y, x.clone(), 64, lay, variant="f32")
+    h2 = dict(lay)
+    h2["lay_h2"], _ = G.ops.d3pm_layer_pack_h2(lay["w1"], lay["w2"], lay["wproj"], lay["wqkv"])
+    with pytest.raises(G.GsddError):
+        G.ops.d3pm_layer(y, x.clone(), 64, h2, variant="x3p")     # only the f16 images were given
+    G.ops.d3pm_layer(y, x.clone(), 64, h2)
 
 
 def test_layer_kernel_weight_range_guard(G):
@@ -789,3 +797,32 @@ def test_attention_arithmetic_modes(G, golden, monkeypatch):
     assert rec["attention_err_flat_trained_peaky[default, L=4096]"] == rec["attention_err_flat_trained_peaky[a8, L=4096]"]
     assert rec["attention_err_flat_trained_peaky[default, L=1024]"] == rec["attention_err_flat_trained_peaky[22, L=1024]"]
     assert rec["fixture_logits_err[22]"] <= rec["fixture_logits_err[11]"]
+
+
+def test_two_streams_run_two_attention_modes_concurrently(G):
+    """The arithmetic mode is an argument of the call, not process state: two HIP streams run the attention kernel in two modes at
+    the same time (hi + lo everywhere on one, hi only on the other, interleaved launches) and each reproduces, bit for bit, what
+    its mode gives when it runs alone."""
+    H, B, L = 16, 2, 2048
+    g = torch.Generator().manual_seed(21)
+    q, k = (torch.randn(H, B * L, 4, generator=g).cuda() * 1.5 for _ in range(2))
+    v = torch.randn(H, B * L, 4, generator=g).cuda()
+    modes = ("22", "11")
+    alone = {}
+    for m in modes:
+        out = torch.empty((B * L, H * 4), device="cuda")
+        G.ops.d3pm_attention(q, k, v, B, L, H, out, ws=G.ops.d3pm_attention_workspace(B, L, H, "cuda"), mode=m)
+        alone[m] = out.clone()
+    assert not torch.equal(alone["22"], alone["11"])                     # the modes do differ on these rows
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in modes]
+    outs = [[torch.empty((B * L, H * 4), device="cuda") for _ in range(4)] for _ in modes]
+    wss = [G.ops.d3pm_attention_workspace(B, L, H, "cuda") for _ in modes]
+    for rep in range(4):
+        for i, m in enumerate(modes):
+            G.ops.d3pm_attention(q, k, v, B, L, H, outs[i][rep], ws=wss[i], mode=m, stream=streams[i])
+    for s_ in streams:
+        s_.synchronize()
+    for i, m in enumerate(modes):
+        for rep in range(4):
+            assert torch.equal(outs[i][rep], alone[m]), (m, rep)

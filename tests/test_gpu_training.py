@@ -290,17 +290,10 @@ def test_rccl_initialises_and_carries_the_bucketed_exchange_on_one_gpu(G):
 def test_attention_backward_matches_fp64_autograd(G, B, L, scale, mode, monkeypatch):
     """dq | dk | dv of softmax(q k^T / 2) v for head dim 4 against torch.autograd in fp64: the fused matrix-pipe kernel (one pass,
     dS through an LDS transpose, partial dQ per 256-key block + reduction; default 96-query chunks, and the selectable 64- / 128-query
-    chunks and 8-wave workgroups), the two-kernel matrix-pipe variant (GSDD_ATTN_BWD_SPLIT) and the VALU kernels (no workspace).
+    chunks and 8-wave workgroups), the two-kernel matrix-pipe variant (variant "split") and the VALU kernels (no workspace).
     L = 320 / 544 cover partial key blocks and query chunks (544 = 2 key blocks + 32, 5 query chunks + 64), scale 3 peaky attention."""
     valu = mode == "valu"
-    for name in ("GSDD_ATTN_BWD_SPLIT", "GSDD_ATTN_BWD_FQC", "GSDD_ATTN_BWD_NW"):
-        monkeypatch.delenv(name, raising=False)
-    if mode == "split":
-        monkeypatch.setenv("GSDD_ATTN_BWD_SPLIT", "1")
-    elif mode in ("fused_q64", "fused_q128"):
-        monkeypatch.setenv("GSDD_ATTN_BWD_FQC", mode[7:])
-    elif mode == "fused_w8":
-        monkeypatch.setenv("GSDD_ATTN_BWD_NW", "8")
+    variant = {"fused": None, "fused_q64": "fqc64", "fused_q128": "fqc128", "fused_w8": "nw8", "split": "split", "valu": "valu"}[mode]
     H = 16
     g = torch.Generator().manual_seed(9)
     q = (torch.randn(B, H, L, 4, generator=g) * scale).double().requires_grad_(True)
@@ -317,7 +310,7 @@ def test_attention_backward_matches_fp64_autograd(G, B, L, scale, mode, monkeypa
     G.ops.d3pm_attention_train(qh, kh, vh, B, L, H, out, lse, ws=G.ops.d3pm_attention_workspace(B, L, H, "cuda"))
     torch.testing.assert_close(out.cpu().double(), rm(o).cpu().double(), atol=2e-5, rtol=0)
     ws = None if valu else G.ops.d3pm_attention_bwd_workspace(B, L, H, "cuda")
-    dqkv = G.ops.d3pm_attention_bwd(qh, kh, vh, out, rm(dO), lse, B, L, H, ws=ws).cpu().double()
+    dqkv = G.ops.d3pm_attention_bwd(qh, kh, vh, out, rm(dO), lse, B, L, H, ws=ws, variant=variant).cpu().double()
     for name, got, want in (("dq", dqkv[:, :64], rm(q.grad)), ("dk", dqkv[:, 64:128], rm(k.grad)), ("dv", dqkv[:, 128:], rm(v.grad))):
         want = want.cpu().double()
         err = (got - want).abs().max().item() / want.abs().max().item()

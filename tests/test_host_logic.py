@@ -469,3 +469,49 @@ def test_bench_reads_attention_traffic_of_its_own_grid_from_the_committed_profil
     assert src is not None and src.endswith("_pmc_traffic.csv")
     assert 1.9e8 < full < 2.2e8 and 0.9e8 < half < 1.2e8
     assert bench.profile_traffic("no_such_kernel", 1) == (None, None)
+
+
+def test_library_reads_no_environment_and_variant_arguments_are_bound(monkeypatch):
+    """The C ABI takes arithmetic mode / kernel variant as arguments (include/gsdd.h): no getenv anywhere under csrc/, the ctypes
+    prototypes carry the extra int, and the Python wrappers translate the debugging environment variables per call -- explicit
+    values only (a typo is an error, not a silent default)."""
+    import glob
+    import gsdd_amd
+    from gsdd_amd import _lib as abi, ops
+    for f in glob.glob(os.path.join(REPO, "gif-synthesis-with-discrete-diffusion_amd", "csrc", "*")):
+        assert "getenv" not in open(f).read(), f
+    header = open(os.path.join(REPO, "include", "gsdd.h")).read()
+    for name, value in (("GSDD_ATTN_AUTO", abi.ATTN_AUTO), ("GSDD_ATTN_P22", abi.ATTN_P22), ("GSDD_ATTN_P11", abi.ATTN_P11),
+                        ("GSDD_ATTN_A8", abi.ATTN_A8), ("GSDD_ATTN_A12", abi.ATTN_A12), ("GSDD_ATTN_F32PV", abi.ATTN_F32PV),
+                        ("GSDD_ATTN_KC256", abi.ATTN_KC256), ("GSDD_LAYER_AUTO", abi.LAYER_AUTO), ("GSDD_LAYER_X3P", abi.LAYER_X3P),
+                        ("GSDD_LAYER_H2", abi.LAYER_H2), ("GSDD_GEMM_EXACT_F32", abi.GEMM_EXACT_F32), ("GSDD_AXIAL_VALU", abi.AXIAL_VALU),
+                        ("GSDD_ATTN_BWD_VALU", abi.ATTN_BWD_VALU), ("GSDD_ATTN_BWD_SPLIT", abi.ATTN_BWD_SPLIT),
+                        ("GSDD_ATTN_BWD_NW8", abi.ATTN_BWD_NW8), ("GSDD_ATTN_BWD_DBG2", abi.ATTN_BWD_DBG2)):
+        m = re.search(r"#define\s+" + name + r"\s+(\d+)", header)
+        assert m and int(m.group(1)) == value, name
+    L = gsdd_amd.lib()
+    assert len(L.gsdd_d3pm_attention.argtypes) == 12 and len(L.gsdd_d3pm_attention_train.argtypes) == 12
+    assert len(L.gsdd_d3pm_attention_bwd.argtypes) == 15 and len(L.gsdd_axial_attention.argtypes) == 10
+    assert [n for n, _ in abi.GemmDesc._fields_][-1] == "flags" and "variant" in dict(abi.LayerDesc._fields_)
+    for var in ("GSDD_ATTN_P", "GSDD_ATTN_V3", "GSDD_ATTN_KC", "GSDD_ATTN_TRAIN_P", "GSDD_LAYER", "GSDD_GEMM_F32", "GSDD_AXIAL_VALU",
+                "GSDD_ATTN_BWD"):
+        monkeypatch.delenv(var, raising=False)
+    assert ops.attn_mode() == abi.ATTN_AUTO and ops.attn_mode("11") == abi.ATTN_P11 and ops.attn_mode(abi.ATTN_A12) == abi.ATTN_A12
+    monkeypatch.setenv("GSDD_ATTN_P", "a8")
+    assert ops.attn_mode() == abi.ATTN_A8 and ops.attn_mode("22") == abi.ATTN_P22          # the keyword wins over the environment
+    monkeypatch.setenv("GSDD_ATTN_P", "a9")
+    with pytest.raises(gsdd_amd.GsddError):
+        ops.attn_mode()
+    monkeypatch.setenv("GSDD_ATTN_TRAIN_P", "22")
+    assert ops.attn_train_mode() == abi.ATTN_P22
+    for bad in ("a8x", "11", "0"):                       # (the advisor's finding: 'a8' used to parse through atoi to 0)
+        monkeypatch.setenv("GSDD_ATTN_TRAIN_P", bad)
+        with pytest.raises(gsdd_amd.GsddError):
+            ops.attn_train_mode()
+    monkeypatch.setenv("GSDD_ATTN_TRAIN_P", "a8")
+    assert ops.attn_train_mode() == abi.ATTN_A8
+    monkeypatch.setenv("GSDD_LAYER", "f32")
+    with pytest.raises(gsdd_amd.GsddError):
+        ops.layer_variant()
+    monkeypatch.setenv("GSDD_GEMM_F32", "1")
+    assert ops.gemm_flags() == abi.GEMM_EXACT_F32 and ops.gemm_flags(False) == 0

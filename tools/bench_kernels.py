@@ -57,19 +57,13 @@ def main():
         ops.d3pm_attention_train(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], Bt, L, H, o, lse, ws=ops.d3pm_attention_workspace(Bt, L, H, dev))
         ws = ops.d3pm_attention_bwd_workspace(Bt, L, H, dev)
         fl = 40.0 * L * L * H * Bt
-        variants = (("fused", {}), ("fused no-LDS-acc", {"GSDD_FUSED_DBG": "1"}), ("fused no-dQ", {"GSDD_FUSED_DBG": "2"}),
-                    ("split", {"GSDD_ATTN_BWD_SPLIT": "1"}))
+        variants = (("fused", None), ("fused no-LDS-acc", "dbg1"), ("fused no-dQ", "dbg2"), ("split", "split"))
         if os.environ.get("GSDD_BENCH_BWD_VARIANTS"):      # e.g. "fused": the counter passes want the shipped variant alone
             keep = os.environ["GSDD_BENCH_BWD_VARIANTS"].split(",")
             variants = tuple(v for v in variants if v[0] in keep)
-        for name, env in variants:
-            for k_ in ("GSDD_FUSED_DBG", "GSDD_ATTN_BWD_SPLIT"):
-                os.environ.pop(k_, None)
-            os.environ.update(env)
-            ms = timeit(lambda: ops.d3pm_attention_bwd(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], o, dO, lse, Bt, L, H, ws=ws), iters=5)
+        for name, variant in variants:
+            ms = timeit(lambda: ops.d3pm_attention_bwd(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], o, dO, lse, Bt, L, H, ws=ws, variant=variant), iters=5)
             print(f"attention bwd B={Bt} L={L} {name}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
-        for k_ in ("GSDD_FUSED_DBG", "GSDD_ATTN_BWD_SPLIT"):
-            os.environ.pop(k_, None)
     if "wgrad" in which:
         Mt = 16 * L
         for (n, k) in [(64, 64), (192, 64), (256, 64), (64, 256), (4096, 64)]:

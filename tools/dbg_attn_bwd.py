@@ -26,13 +26,8 @@ def run(B, L, scale, H=16):
     ops.d3pm_attention_train(qh, kh, vh, B, L, H, out, lse, ws=ops.d3pm_attention_workspace(B, L, H, "cuda"))
     res = {}
     for mode in ("fused", "split"):
-        if mode == "split":
-            os.environ["GSDD_ATTN_BWD_SPLIT"] = "1"
-        else:
-            os.environ.pop("GSDD_ATTN_BWD_SPLIT", None)
         ws = ops.d3pm_attention_bwd_workspace(B, L, H, "cuda")
-        res[mode] = ops.d3pm_attention_bwd(qh, kh, vh, out, rm(dO), lse, B, L, H, ws=ws).cpu().double()
-    os.environ.pop("GSDD_ATTN_BWD_SPLIT", None)
+        res[mode] = ops.d3pm_attention_bwd(qh, kh, vh, out, rm(dO), lse, B, L, H, ws=ws, variant="split" if mode == "split" else None).cpu().double()
     want = {"dq": rm(q.grad).cpu().double(), "dk": rm(k.grad).cpu().double(), "dv": rm(v.grad).cpu().double()}
     for i, name in enumerate(("dq", "dk", "dv")):
         w = want[name]
