@@ -64,7 +64,7 @@ class LayerDesc(C.Structure):
     _fields_ = [
         ("y", _p), ("x", _p), ("M", _i64), ("L", _i), ("n_embd", _i), ("hidden", _i), ("cvec", _p),
         ("wproj", _p), ("bproj", _p), ("ln2_g", _p), ("ln2_b", _p), ("w1", _p), ("b1", _p), ("w2", _p), ("b2", _p),
-        ("ada", _p), ("t2", _p), ("wqkv", _p), ("bqkv", _p), ("qkv", _p), ("w2_x3", _p), ("wqkv_x3", _p), ("kv_img", _p),
+        ("ada", _p), ("t2", _p), ("wqkv", _p), ("bqkv", _p), ("qkv", _p), ("w2_x3", _p), ("wqkv_x3", _p), ("kv_img_bytes", _i64), ("kv_img", _p),
         ("layer_h2", _p), ("wqkv_h2", _p), ("variant", _i), ("range_flag", _p),
     ]
 

@@ -1215,7 +1215,8 @@ extern "C" int gsdd_d3pm_layer(const gsdd_layer_desc* d, void* stream) {
     a.knorm = nullptr;
     a.ksum = nullptr;
     if (has_qkv && d->kv_img != nullptr) {
-        GSDD_CHECK_ARG(d->L % 32 == 0, "kv_img needs L % 32 == 0");
+        GSDD_CHECK_ARG(d->L % 32 == 0 && d->M % d->L == 0, "kv_img needs L % 32 == 0 and whole batch elements");
+        GSDD_CHECK_ARG(d->kv_img_bytes >= gsdd_d3pm_attention_workspace_bytes((int)(d->M / d->L), d->L, 16), "kv_img too small");
         a.kimg = reinterpret_cast<uint4*>(d->kv_img);
         a.vimg = a.kimg + d->M * 16 * 2;                      // K image: 2 uint4 per (row, head), 16 heads
         a.knorm = kv_image_knorm(d->kv_img, d->M * 16);

@@ -129,6 +129,10 @@ class Text2ImageTransformer(nn.Module):
         # the fastest and data-independent: within the 1e-4 logits contract on every pinned case, not within the kernel's own 2e-5 bar
         # on peaked rows.  The environment variable GSDD_ATTN_P overrides None.
         self.attention_mode = None
+        # set by demote_to_x3p (an activation left the f16 operand range of the default layer kernel): this model keeps the bf16x3 layer
+        # kernel across re-packs -- every optimizer step re-packs -- until a state dict is loaded into it
+        self._range_demoted = False
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_range_demoted", False))
 
     @staticmethod
     def _init_weights(module):                       # transformer_utils.py:363-371
@@ -185,6 +189,8 @@ class Text2ImageTransformer(nn.Module):
         want = os.environ.get("GSDD_LAYER", "h2")
         if want not in ("h2", "x3p"):
             raise GsddError(f"GSDD_LAYER={want!r}: the fused layer kernels are 'h2' (f16 hi + lo images) and 'x3p' (bf16x3 images)")
+        if want == "h2" and self._range_demoted:
+            want = "x3p"
         if want == "h2" and "lay_h2" not in layers[0] and "w2_x3" not in layers[0]:
             # the f16 images hold 2^8 w: a weight of 255 or more would overflow them (checked once per weight set; such a model takes
             # the bf16x3 kernel, which has f32's range)
@@ -204,7 +210,9 @@ class Text2ImageTransformer(nn.Module):
     def demote_to_x3p(self, stream=None):
         """The f16 hi + lo layer kernel carries activations as 16 a in f16: |a| >= 4094 (an outlier LN / GELU2 / attention output of a
         trained checkpoint) overflows.  The kernel flags that (LayerDesc.range_flag) and the caller lands here: this weight set takes the
-        bf16x3 kernel, which has f32's range, until the weights change.  -> True if anything changed."""
+        bf16x3 kernel, which has f32's range, until a state dict is loaded (the decision survives re-packs: a training loop's validation
+        pass would otherwise try the f16 images again after every optimizer step and run everything twice).  -> True if anything changed."""
+        self._range_demoted = True
         layers = self.packed()["layers"]
         if not layers or "lay_h2" not in layers[0]:
             return False
@@ -215,8 +223,10 @@ class Text2ImageTransformer(nn.Module):
         return True
 
     def run_checked(self, tok, condv, Te, t2, ws, rep=1, stream=None):
-        """run() + the range screen of the f16 hi + lo layer kernel (one 4-byte read back: eager callers only; sample() checks
-        once per call, after its captured loop)."""
+        """run() + the range screen of the f16 hi + lo layer kernel (one 4-byte read back: eager callers only -- forward(),
+        p_sample_tokens, the no-grad objective; sample() checks once per call, after its captured loop, and the gradient path
+        (d3pm_train.py) does not use the fused layer kernel at all).  The read is a host synchronisation, kept because the caller
+        gets these logits: a demoted model (see demote_to_x3p) pays it without ever re-running."""
         logits = self.run(tok, condv, Te, t2, ws, rep=rep, stream=stream)
         if int(ws["range"].item()) != 0:
             ws["range"].zero_()
@@ -455,15 +465,18 @@ class DiffusionTransformer(nn.Module):
                 raise GsddError("non-finite activations in the denoiser (inf / NaN in the inputs or weights?)")
             if trace is not None:
                 del trace[mark:]
-            self.noise_stream -= self.num_timesteps
+            self.noise_stream -= self._last_draws
             out = self._sample_once(*args, trace=trace, **kw)
         return out
 
     def _sample_once(self, condition_token, condition_mask, condition_embed, cf_condition_embed, content_token=None,
                      filter_ratio=0.5, return_logits=False, use_graph=True, trace=None, **kwargs):
-        if int(self.num_timesteps * filter_ratio) != 0:
-            raise NotImplementedError("only filter_ratio=0 (full-mask start) is used by the reference call site "
-                                      "(discrete_diffusion.py:53-60)")
+        # filter_ratio > 0: start from content_token noised to t = start_step - 1 and run start_step reverse steps
+        # (diffusion_transformer.py:590-592, :626-634; the reference's own loop there passes p_sample four of its six positional
+        # parameters and raises TypeError -- this is the behaviour that branch is written for, one p_sample per step)
+        start_step = int(self.num_timesteps * filter_ratio)
+        if start_step != 0 and content_token is None:
+            raise GsddError("filter_ratio > 0 needs content_token (the tokens to start from)")
         dev = self.device
         if dev.type != "cuda":
             raise GsddError("sampling runs on the HIP path only: move the module to a ROCm device")
@@ -478,6 +491,12 @@ class DiffusionTransformer(nn.Module):
         # through the same arithmetic as the stacked pass, at half the denoiser work.  (One host comparison per sample() call;
         # GSDD_CFG_DEDUPE=0 keeps the two copies.)
         same_cond = (guided and os.environ.get("GSDD_CFG_DEDUPE", "1") != "0" and cf.shape == cond.shape and bool(torch.equal(cond, cf)))
+        n_steps = start_step if start_step != 0 else T
+        stream0 = self.noise_stream + (1 if start_step != 0 else 0)      # the partially noised start spends one draw on q_sample
+        if start_step != 0:
+            x0_start = content_token.to(dev).long().reshape(B, L).contiguous()
+            if int(x0_start.min()) < 0 or int(x0_start.max()) > K:
+                raise GsddError("content_token outside [0, num_embed]")
         rep = 2 if (guided and not same_cond) else 1
         self._last_cfg_dedupe = same_cond
         tr = self.transformer
@@ -508,12 +527,18 @@ class DiffusionTransformer(nn.Module):
                 ws = tr.workspace(rep * Bs, L, dev, rep=rep)
                 redo_counters.append(ws["redo"])
                 range_flags.append(ws["range"])
-                tok = torch.full((Bs, L), K, dtype=torch.int64, device=dev)               # all [MASK] (:613-618)
-                t2 = torch.full((rep * Bs,), T - 1, dtype=torch.int64, device=dev)
-                sid = torch.tensor([self.noise_stream], dtype=torch.int64, device=dev)
+                t2 = torch.full((rep * Bs,), n_steps - 1, dtype=torch.int64, device=dev)
+                sid = torch.tensor([stream0], dtype=torch.int64, device=dev)
                 sched = self._sched()
                 M = Bs * L
                 row0 = (self.row_offset + ln * Bs) * L
+                if start_step == 0:
+                    tok = torch.full((Bs, L), K, dtype=torch.int64, device=dev)           # all [MASK] (:613-618)
+                else:                                                                    # q_sample at t = start_step - 1 (:628-630)
+                    tok = torch.empty((Bs, L), dtype=torch.int64, device=dev)
+                    ops.d3pm_q_sample(x0_start[sl].contiguous(), tok, sched, t2[:Bs].contiguous(),
+                                      torch.tensor([self.noise_stream], dtype=torch.int64, device=dev), K=K, T=T,
+                                      seed=self.noise_seed, row0=row0, stream=st)
 
                 def one_step(tok=tok, condv=condv, Te=Te, t2=t2, ws=ws, sid=sid, M=M, row0=row0, st=st):
                     logits = tr.run(tok, condv, Te, t2, ws, rep=rep, stream=st)
@@ -529,13 +554,13 @@ class DiffusionTransformer(nn.Module):
                     g.end(st)
                     graphs.append(g)
                 else:
-                    for _ in range(T):
+                    for _ in range(n_steps):
                         one_step()
                         if trace is not None:
                             trace.append(tok.clone())
                 toks.append(tok)
         if graphs:
-            for _ in range(T - 1):              # the lanes' replays are issued alternately so that both queues stay fed
+            for _ in range(n_steps - 1):        # the lanes' replays are issued alternately so that both queues stay fed
                 for ln, g in enumerate(graphs):
                     g.launch(self._streams[ln])
             self._last_graph = graphs[0]
@@ -547,7 +572,8 @@ class DiffusionTransformer(nn.Module):
         self._redo_counters = redo_counters     # attention chunk-redo events of this call, one device counter per lane
         self._range_flags = range_flags
         self._last_lanes = lanes
-        self.noise_stream += T
+        self._last_draws = n_steps + (1 if start_step != 0 else 0)
+        self.noise_stream += self._last_draws
         out = {"content_token": tok}
         if return_logits:
             raise NotImplementedError("return_logits is unused by the reference call sites")

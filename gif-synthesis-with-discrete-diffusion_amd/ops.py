@@ -275,6 +275,7 @@ def d3pm_layer(y, x, L, lay, cvec=None, nxt=None, t2=None, qkv=None, kv_img=None
         d.wqkv_x3 = ptr(nxt.get("wqkv_x3"))
         d.wqkv_h2 = ptr(nxt.get("wqkv_h2"))
         d.kv_img = ptr(kv_img)
+        d.kv_img_bytes = 0 if kv_img is None else kv_img.numel() * kv_img.element_size()
     d.range_flag = ptr(range_flag)
     d.variant = layer_variant(variant)
     check(lib().gsdd_d3pm_layer(C.byref(d), stream_ptr(stream)))

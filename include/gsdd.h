@@ -237,6 +237,7 @@ typedef struct {
     const void* w2_x3;          /* gsdd_d3pm_layer_pack images (bf16x3 MFMA fragments) of this block's w2 + wproj and of the */
     const void* wqkv_x3;        /* next block's wqkv: ready-made matrix operands streamed through LDS.  One of the two image */
                                 /* sets (these or layer_h2 / wqkv_h2) must be given                                           */
+    int64_t kv_img_bytes;       /* size of kv_img in bytes: at least gsdd_d3pm_attention_workspace_bytes(M / L, L, 16)          */
     void* kv_img;               /* optional (L % 32 == 0): the attention workspace of the next                                  */
                                 /* block.  k and v are then written there as the matrix-pipe kernel's pre-split images instead */
                                 /* of f32 rows of qkv, and gsdd_d3pm_attention is called with k = v = NULL (no prep pass)      */

@@ -216,6 +216,26 @@ def sample(B, L, cond, cf_cond, sd, scale, seed, n_head=16, trace=None, row0=0, 
     return tok
 
 
+def sample_from(content_token, filter_ratio, cond, cf_cond, sd, scale, seed, n_head=16, row0=0, stream0=0):
+    """DiffusionTransformer.sample with filter_ratio > 0 and a content_token (diffusion_transformer.py:590-592, :626-634): start_step =
+    int(T * filter_ratio); x_t = q_sample(content_token, t = start_step - 1) (:629-630, Gumbel arg-max of q_pred: one draw, stream
+    `stream0`), then the start_step reverse steps t = start_step - 1 ... 0 (draws stream0 + 1 ...).  The reference's loop calls
+    `self.p_sample(log_z, cond_emb, cf_cond_emb, t)` with four of p_sample's six positional parameters (:634 vs :304-305) and so
+    raises TypeError as written; this restates what that branch is written to do (the upstream VQ-Diffusion behaviour: one p_sample
+    per step, as in the filter_ratio = 0 branch)."""
+    T = sd["log_at"].shape[0]
+    K1 = sd["transformer.content_emb.emb.weight"].shape[0]
+    start = int(T * filter_ratio)
+    assert start > 0
+    B = content_token.shape[0]
+    t = torch.full((B,), start - 1, dtype=torch.long)
+    tok = gumbel_argmax(q_pred(index_to_log_onehot(content_token, K1), t, sd), seed, stream0, row0=row0)
+    for i, step in enumerate(range(start - 1, -1, -1)):
+        t = torch.full((B,), step, dtype=torch.long)
+        tok, _ = p_sample_step(tok, cond, cf_cond, t, sd, scale, seed, stream=stream0 + 1 + i, n_head=n_head, row0=row0)
+    return tok
+
+
 # ----------------------------------------------------------------------------- training loss
 def train_loss(x0, cond, t, pt, sd, seed, stream, aux_weight=5.0e-4, adaptive_aux=True, mask_weight=(1, 1),
                n_head=16):

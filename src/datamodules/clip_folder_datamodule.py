@@ -18,6 +18,18 @@ import numpy as np
 import torch
 
 
+class ShardedLoader:
+    """The batches of ONE rank, in order (an iterator).  `gsdd_sharded` tells the runner that this loader has already dealt the
+    batches to the ranks (src/tasks/runner.py::Trainer._batches deals any other iterable itself)."""
+    gsdd_sharded = True
+
+    def __init__(self, it, shard):
+        self._it, self.shard = it, shard
+
+    def __iter__(self):
+        return self._it
+
+
 class ClipFolderDataset:
     def __init__(self, data_folder, sequence_length, split="train", resolution=64, frames_between_clips=100, class_names=None, **kw):
         self.sequence_length, self.resolution = sequence_length, resolution
@@ -67,13 +79,18 @@ class ClipFolderDataModule:
         self.epoch = int(epoch)                          # the shuffle is a function of (shuffle_seed, epoch)
 
     def _loader(self, split, shuffle):
+        return ShardedLoader(self._batches(split, shuffle), self.shard)
+
+    def _batches(self, split, shuffle):
         from gsdd_amd.data import preprocess
         ds = ClipFolderDataset(split=split, **self.args)
         order = list(range(len(ds)))
         if shuffle:
             order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(self.shuffle_seed + self.epoch)).tolist()
         rank, world = self.shard
-        nbatch = (len(order) + self.batch_size - 1) // self.batch_size
+        # data parallel: full batches only -- a short trailing batch would give one rank a different local batch size, i.e. overlapping
+        # noise rows (row_offset = rank * local batch) and an unweighted gradient mean; one process keeps it, as the reference's loader does
+        nbatch = (len(order) + self.batch_size - 1) // self.batch_size if world == 1 else len(order) // self.batch_size
         for b in range(rank, (nbatch // world) * world, world):
             i = b * self.batch_size
             items = [ds[j] for j in order[i:i + self.batch_size]]

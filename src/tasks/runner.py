@@ -52,8 +52,9 @@ class Trainer:
         """Batches are dealt round-robin to the ranks, in whole rounds: a trailing round that cannot serve every rank is dropped,
         so all ranks take the same number of steps (every step holds collectives).  A datamodule that shards by itself
         (`set_shard(rank, world)`: this rank only reads and preprocesses its own batches, like a DistributedSampler) hands over
-        exactly those batches; any other iterable is dealt here, every rank walking all of it."""
-        if self._dm_sharded:
+        exactly those batches and marks its loaders (`gsdd_sharded`); any other iterable -- also one handed over next to such a
+        datamodule -- is dealt here, every rank walking all of it."""
+        if self._dm_sharded and getattr(loader, "gsdd_sharded", False):
             for i, batch in enumerate(loader):
                 if self.limit_batches is not None and i >= self.limit_batches:
                     break

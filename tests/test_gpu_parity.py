@@ -826,3 +826,32 @@ def test_two_streams_run_two_attention_modes_concurrently(G):
     for i, m in enumerate(modes):
         for rep in range(4):
             assert torch.equal(outs[i][rep], alone[m]), (m, rep)
+
+
+@pytest.mark.parametrize("filter_ratio", [0.3, 0.05])
+def test_sample_from_partially_noised_start(G, golden, filter_ratio):
+    """sample(content_token=..., filter_ratio > 0) (diffusion_transformer.py:590-592, :626-634): q_sample of the given tokens at
+    t = int(T * filter_ratio) - 1, then that many reverse steps.  The reference's own loop for this branch raises TypeError (it passes
+    p_sample four of its six positional parameters), so the pin is the oracle's restatement of what the branch is written to do, built
+    from pieces that are themselves pinned to the reference (q_pred, Gumbel arg-max, p_sample_step): tokens bit-exact, eager and
+    captured, and the noise stream advances by the draws spent (one q_sample + the steps)."""
+    from oracle import d3pm as od
+    sd, a, cfg = golden("d3pm_L64")
+    dm = build_d3pm(G, sd, cfg)
+    B, L, K, T = cfg["B"], cfg["L"], cfg["K"], cfg["T"]
+    g = torch.Generator().manual_seed(31)
+    x0 = torch.randint(0, K, (B, L), generator=g)
+    cond = torch.from_numpy(a["step_cond"])
+    with torch.no_grad():
+        want = od.sample_from(x0, filter_ratio, cond, torch.zeros_like(cond), sd, cfg["guidance"], cfg["noise_seed"], stream0=7)
+    steps = int(T * filter_ratio)
+    for use_graph in (False, True):
+        dm.set_noise(cfg["noise_seed"], stream=7)
+        got = dm.sample(["a"] * B, None, cond.cuda(), torch.zeros_like(cond).cuda(), content_token=x0.cuda(), filter_ratio=filter_ratio,
+                        use_graph=use_graph)["content_token"].cpu()
+        assert torch.equal(got, want), f"use_graph={use_graph}: {(got != want).sum().item()} tokens differ"
+        assert dm.noise_stream == 7 + 1 + steps
+    # (the last step, t = 0, draws from the model's own x_0 prediction -- the posterior's t - 1 wrap -- so with random weights few of
+    # the given tokens survive: that is the reference's arithmetic, not a property to assert.)  No tokens given: an error
+    with pytest.raises(G.GsddError):
+        dm.sample(["a"] * B, None, cond.cuda(), torch.zeros_like(cond).cuda(), content_token=None, filter_ratio=filter_ratio)

@@ -385,6 +385,25 @@ def test_clip_folder_datamodule_shards_whole_rounds(tmp_path, monkeypatch):
         for r, (b, read) in enumerate(per_rank):
             assert b == [single[i * world + r] for i in range(rounds)]
             assert len(read) == 2 * rounds            # only its own clips were read and preprocessed
+    # an odd clip count: the single process keeps the short trailing batch (as the reference's loader does); data-parallel ranks only
+    # ever see full batches (a short one would shift that rank's noise rows onto another rank's and unweight the gradient mean)
+    np.save(tmp_path / "train" / "b" / "clip5.npy", rng.integers(0, 255, (4, 8, 8, 3), dtype=np.uint8))
+    single, _ = batches(0, 1)
+    assert [len(b) for b in single] == [2, 2, 2, 2, 2, 1]
+    for world in (2, 3):
+        for r in range(world):
+            b, _ = batches(r, world)
+            assert len(b) == 5 // world and all(len(x) == 2 for x in b)
+    # the runner takes a loader's word for being sharded only from the loader itself
+    from src.tasks.runner import Trainer
+    dm = ClipFolderDataModule(str(tmp_path), sequence_length=4, resolution=8, batch_size=2, device="cpu", shuffle_seed=3)
+    dm.set_shard(1, 2)
+    assert getattr(dm.train_dataloader(), "gsdd_sharded", False)
+    tr = Trainer.__new__(Trainer)
+    tr._dm_sharded, tr.limit_batches, tr.rank, tr.world = True, None, 1, 2
+    foreign = [10, 11, 12, 13, 14]                     # not the datamodule's: dealt by the runner, whole rounds only
+    assert list(tr._batches(foreign)) == [(0, 11), (1, 13)]
+    assert [i for i, _ in tr._batches(dm.train_dataloader())] == [0, 1]
 
 
 def test_clip_text_provider_runs_a_supplied_local_tower(tmp_path):
@@ -515,3 +534,15 @@ def test_library_reads_no_environment_and_variant_arguments_are_bound(monkeypatc
         ops.layer_variant()
     monkeypatch.setenv("GSDD_GEMM_F32", "1")
     assert ops.gemm_flags() == abi.GEMM_EXACT_F32 and ops.gemm_flags(False) == 0
+
+
+def test_host_side_of_the_c_abi_under_address_and_ub_sanitizers():
+    """tools/host_asan: the C-ABI wrappers of csrc/*.hip compiled host-only with -fsanitize=address,undefined against a stub HIP runtime
+    (no kernel runs).  The driver calls every family of entry points with valid descriptors at the workload's sizes, with each workspace
+    contract violated by one byte (-> GSDD_E_ARG and no launch), with bad pointers / sizes / variant values, and through a failing
+    hipFuncSetAttribute (reported, then retried).  A sanitizer report or a wrong return code fails the run."""
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run(["bash", os.path.join(REPO, "tools", "host_asan", "build.sh"), "run"], cwd=REPO, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "0 failed" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
