@@ -61,7 +61,9 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
     """L = 4096, K = 4096, 19 layers, both weight scales: logits within 1e-4 of the oracle, and FIVE guided reverse steps -- the loop's
     first (t = 99, all [MASK]), a teacher-forced chain of three mid-chain steps (the oracle's tokens of step s feed step s+1 on both
     sides, so one flipped arg-max cannot hide the next steps) and a late one (t = 5, mostly unmasked): a token may differ from the oracle's only where the oracle's own top-2 margin is below 1e-5 -- the measured counts,
-    margins and errors go to the parity report."""
+    margins and errors go to the parity report.  Both attention arithmetic modes are held to the path's contract (logits within
+    1e-4, tokens bit-identical): the default, and attention_mode '11' (P as f16 hi only in every tile), which is what pins '11' as a
+    documented mode at the workload's own size."""
     from oracle import d3pm as od
     dm = full_d3pm(G, 0, scale_weights)
     sd = {k: v.detach().clone() for k, v in dm.state_dict().items()}
@@ -75,7 +77,10 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
     tok_late[torch.rand(B, L, generator=g) < 0.03] = K
     dm = dm.cuda()
     dm.set_noise(77)
-    rec = {"steps": [], "logits_err": [], "logits_err_uncond": [], "mismatches": [], "min_margin": [], "mismatch_margins": []}
+    # every oracle step (tens of seconds of host CPU) is computed once and checked against BOTH attention arithmetic modes: the default
+    # (adaptive lo half: 'a8' at this length) and '11' (f16 hi only in every tile: the documented fast mode, data-independent cost)
+    modes = (None, "11")
+    recs = {m: {"steps": [], "logits_err": [], "logits_err_uncond": [], "mismatches": [], "min_margin": [], "mismatch_margins": []} for m in modes}
     # the first step of the loop (t = 99, every position [MASK], -inf rows), three mid-chain steps, one late step
     for s, step in enumerate((99, 41, 40, 39, 5)):
         t = torch.tensor([step])
@@ -89,19 +94,25 @@ def test_full_size_denoiser_logits_and_step(G, scale_weights):
             tok_in = want_tok                                            # teacher forcing: continue from the oracle's tokens
         tok = tok_in
         want_tok, margin, want_c, want_u = _oracle_step(od, tok, cond, t, sd, 77, 3 + s, K, first=(step == 99))
-        got_c = dm.transformer(tok.cuda(), cond.cuda(), t.cuda()).cpu()
-        got_u = dm.transformer(tok.cuda(), torch.zeros_like(cond).cuda(), t.cuda()).cpu()
-        err_c, err_u = (got_c - want_c).abs().max().item(), (got_u - want_u).abs().max().item()
-        out = dm.p_sample_tokens(tok.cuda(), cond.cuda(), torch.zeros_like(cond).cuda(), t.cuda(), 3 + s).cpu()
-        mism = out != want_tok
-        rec["steps"].append(step); rec["logits_err"].append(err_c); rec["logits_err_uncond"].append(err_u)
-        rec["mismatches"].append(int(mism.sum())); rec["min_margin"].append(margin.min().item())
-        rec["mismatch_margins"].append(margin[mism].tolist())
-    parity_report(f"full_size_d3pm_chain[scale_weights={scale_weights}]", rec)
-    assert max(rec["logits_err"] + rec["logits_err_uncond"]) < 1e-4, rec
-    for margins in rec["mismatch_margins"]:
-        assert all(m < 1e-5 for m in margins), f"token differs away from a near-tie: {rec}"
-    assert sum(rec["mismatches"]) == 0, f"tokens differ (all at near-ties, margins {rec['mismatch_margins']})"
+        for mode in modes:
+            dm.transformer.attention_mode = mode
+            rec = recs[mode]
+            got_c = dm.transformer(tok.cuda(), cond.cuda(), t.cuda()).cpu()
+            got_u = dm.transformer(tok.cuda(), torch.zeros_like(cond).cuda(), t.cuda()).cpu()
+            err_c, err_u = (got_c - want_c).abs().max().item(), (got_u - want_u).abs().max().item()
+            out = dm.p_sample_tokens(tok.cuda(), cond.cuda(), torch.zeros_like(cond).cuda(), t.cuda(), 3 + s).cpu()
+            mism = out != want_tok
+            rec["steps"].append(step); rec["logits_err"].append(err_c); rec["logits_err_uncond"].append(err_u)
+            rec["mismatches"].append(int(mism.sum())); rec["min_margin"].append(margin.min().item())
+            rec["mismatch_margins"].append(margin[mism].tolist())
+    dm.transformer.attention_mode = None
+    for mode in modes:
+        rec = recs[mode]
+        parity_report(f"full_size_d3pm_chain[scale_weights={scale_weights}" + ("" if mode is None else f", attention_mode={mode}") + "]", rec)
+        assert max(rec["logits_err"] + rec["logits_err_uncond"]) < 1e-4, (mode, rec)
+        for margins in rec["mismatch_margins"]:
+            assert all(m < 1e-5 for m in margins), f"mode {mode}: token differs away from a near-tie: {rec}"
+        assert sum(rec["mismatches"]) == 0, f"mode {mode}: tokens differ (all at near-ties, margins {rec['mismatch_margins']})"
 
 
 @pytest.mark.parametrize("res", [128, 64])      # C2's clip shape, and config C1 (one 16x64x64 clip, encode -> quantise -> decode)

@@ -314,13 +314,16 @@ def test_identical_guidance_copies_run_once(G, golden, monkeypatch):
     assert not dm._last_cfg_dedupe and np.array_equal(out["content_token"].cpu().numpy(), a["loop_tokens"])
 
 
-def test_long_sequence_loop_tokens_bit_exact_vs_reference(G, golden):
+@pytest.mark.parametrize("attention_mode", [None, "11"])
+def test_long_sequence_loop_tokens_bit_exact_vs_reference(G, golden, attention_mode):
     """The reference's own 100-step reverse loop at L = 2048 (`d3pm_L2048`: one clip, two layers, K = 32, trained-like weights),
     where the attention kernel runs its default adaptive P arithmetic (f16 hi, lo where the norm bound / the measured test ask for
     it): the eager per-step trace and the captured hipGraph's final tokens equal the reference's, token for token, and the
-    teacher-forced step's logits are within 1e-4.  This is the reference-generated pin of that arithmetic over a whole chain."""
+    teacher-forced step's logits are within 1e-4.  This is the reference-generated pin of that arithmetic over a whole chain -- and,
+    with attention_mode '11' (P as f16 hi only in every tile), of the documented fast mode."""
     sd, a, cfg = golden("d3pm_L2048")
     dm = build_d3pm(G, sd, cfg)
+    dm.transformer.attention_mode = attention_mode
     cond = dev(a["step_cond"])
     B = cfg["B"]
     logits = dm.transformer(dev(a["step_xt"]), cond, dev(a["step_t"]))
@@ -330,7 +333,7 @@ def test_long_sequence_loop_tokens_bit_exact_vs_reference(G, golden):
     out = dm.sample(["a"] * B, None, cond, torch.zeros_like(cond), filter_ratio=0, trace=trace)
     got = np.stack([x.cpu().numpy() for x in trace])
     bad = (got != a["loop_trace"]).reshape(got.shape[0], -1)
-    parity_report("long_sequence_loop_L2048", {"logits_err": lerr, "steps": int(got.shape[0]), "positions": int(got.shape[1] * got.shape[2]),
+    parity_report("long_sequence_loop_L2048" + ("" if attention_mode is None else f"[attention_mode={attention_mode}]"), {"logits_err": lerr, "steps": int(got.shape[0]), "positions": int(got.shape[1] * got.shape[2]),
                                                "trace_mismatches": int(bad.sum()), "first_bad_step": int(np.nonzero(bad.any(1))[0][0]) if bad.any() else -1,
                                                "min_step_margin": float(a["step_margin"].min()), "redo_events": dm.attention_redo_events()})
     assert lerr < LOGIT_TOL, lerr

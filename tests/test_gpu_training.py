@@ -145,6 +145,52 @@ def test_loss_gradients_full_size_two_layers(G):
     assert worst[1] < 2e-3, worst
 
 
+def test_training_forward_attention_modes_agree_at_long_sequences(G, monkeypatch):
+    """The training forward's default attention arithmetic at L >= 2048 is the adaptive one (lo half only where a tile can hold a
+    probability above 2^-8 of its row sum); GSDD_ATTN_TRAIN_P=22 forces hi + lo everywhere.  Loss and every parameter gradient of the
+    two must agree to the documented bar (output error <= 2e-5 of the row scale: far below what the gradient parity tests resolve) at
+    a length where the default actually is adaptive; anything but '22' / 'a8' is refused."""
+    from gsdd_amd.d3pm_train import D3PMTrainer
+    from tests.conftest import parity_report
+    torch.manual_seed(17)
+    K, L, B = 64, 2048, 2
+    d = G.DalleMaskImageEmbedding(num_embed=K, spatial_size=[64, 32], embed_dim=64)
+    tr = G.Text2ImageTransformer(dalle=d, n_layer=2, n_embd=64, n_head=16, content_seq_len=L, block_activate="GELU2",
+                                 content_spatial_size=[64, 32], condition_dim=512, diffusion_step=100)
+    g = torch.Generator().manual_seed(18)
+    for mod in tr.modules():
+        if isinstance(mod, torch.nn.Linear):
+            mod.weight.data = torch.randn(mod.weight.shape, generator=g) * (1.0 / mod.in_features ** 0.5)
+            mod.bias.data = 0.1 * torch.randn(mod.bias.shape, generator=g)
+        elif isinstance(mod, torch.nn.Embedding):
+            mod.weight.data = torch.randn(mod.weight.shape, generator=g) * 0.5
+    dm = G.DiffusionTransformer(transformer=tr, diffusion_step=100, alpha_init_type="alpha1", auxiliary_loss_weight=5e-4,
+                                adaptive_auxiliary_loss=True, guidance_scale=2, content_seq_len=L).cuda()
+    x0 = torch.randint(0, K, (B, L), generator=g).cuda()
+    cond = torch.randn(B, 1, 512, generator=g).cuda()
+    t, pt = torch.tensor([30, 77]).cuda(), (torch.ones(B) / 100).cuda()
+    res = {}
+    for mode in (None, "22", "a8"):
+        if mode is None:
+            monkeypatch.delenv("GSDD_ATTN_TRAIN_P", raising=False)
+        else:
+            monkeypatch.setenv("GSDD_ATTN_TRAIN_P", mode)
+        dm.set_noise(5, stream=0)
+        loss, grads = D3PMTrainer(dm).loss_and_grads(x0, cond, t=t, pt=pt)
+        res[mode] = (loss.item(), {k: v.clone() for k, v in grads.items()})
+    assert res[None][0] == res["a8"][0] and all(torch.equal(res[None][1][k], res["a8"][1][k]) for k in res["a8"][1])   # default = a8 here
+    gmax = max(v.abs().max().item() for v in res["22"][1].values())
+    worst = max(((res[None][1][k] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), k) for k, w in res["22"][1].items())
+    parity_report("train_attention_default_vs_hi_lo_L2048", {"loss_default": res[None][0], "loss_hi_lo": res["22"][0],
+                                                             "worst_relative_gradient_difference": worst[0], "worst_parameter": worst[1]})
+    assert abs(res[None][0] - res["22"][0]) <= 2e-5 * abs(res["22"][0])
+    assert worst[0] < 5e-4, worst
+    monkeypatch.setenv("GSDD_ATTN_TRAIN_P", "11")
+    with pytest.raises(G.GsddError):
+        D3PMTrainer(dm).loss_and_grads(x0, cond, t=t, pt=pt)
+    monkeypatch.delenv("GSDD_ATTN_TRAIN_P")
+
+
 def test_adam_step_matches_torch(G, golden):
     from gsdd_amd.d3pm_train import D3PMTrainer
     sd, a, cfg = golden("d3pm_L64")
