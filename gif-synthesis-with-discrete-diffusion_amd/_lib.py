@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("GSDD_LIB_PATH") or os.path.join(_HERE, "libgsdd.so") 
 _lib = None
 
 EXPORTS = [
-    "gsdd_last_error", "gsdd_version", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows", "gsdd_preprocess_clip",
+    "gsdd_last_error", "gsdd_version", "gsdd_abi_sizeof", "gsdd_gemm", "gsdd_row_stats", "gsdd_ncdhw_to_rows", "gsdd_preprocess_clip",
     "gsdd_axial_attention", "gsdd_pool3d", "gsdd_nearest_code", "gsdd_nearest_code_workspace_bytes", "gsdd_bn_train_workspace_bytes", "gsdd_bn_train",
     "gsdd_codebook_ema", "gsdd_code_perplexity", "gsdd_mse", "gsdd_conv_wgrad", "gsdd_bn_relu_bwd_workspace_bytes", "gsdd_bn_relu_bwd",
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
@@ -91,6 +91,14 @@ def lib():
                             "there is no CPU fallback for this path")
         L = C.CDLL(LIB_PATH)
         L.gsdd_last_error.restype = C.c_char_p
+        if not hasattr(L, "gsdd_abi_sizeof"):
+            raise GsddError(f"{LIB_PATH} predates this binding (no gsdd_abi_sizeof): rebuild it with ./build.sh")
+        L.gsdd_abi_sizeof.argtypes, L.gsdd_abi_sizeof.restype = [_i], _i64
+        for which, (name, cls) in enumerate((("gsdd_gemm_desc", GemmDesc), ("gsdd_layer_desc", LayerDesc), ("gsdd_step_desc", StepDesc),
+                                             ("gsdd_train_desc", TrainDesc))):
+            if L.gsdd_abi_sizeof(which) != C.sizeof(cls):
+                raise GsddError(f"{LIB_PATH} was built from another revision of include/gsdd.h: sizeof({name}) is {L.gsdd_abi_sizeof(which)} "
+                                f"there and {C.sizeof(cls)} in this binding -- rebuild it with ./build.sh")
         L.gsdd_gemm.argtypes = [C.POINTER(GemmDesc), _p]
         L.gsdd_row_stats.argtypes = [_p, _i64, _i, C.c_float, _p, _p]
         L.gsdd_ncdhw_to_rows.argtypes = [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p]

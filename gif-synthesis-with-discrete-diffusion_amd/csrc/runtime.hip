@@ -9,7 +9,16 @@ void set_error(const std::string& s) { g_err = s; }
 using namespace gsdd;
 
 extern "C" const char* gsdd_last_error(void) { return g_err.c_str(); }
-extern "C" int gsdd_version(void) { return 100; }
+extern "C" int gsdd_version(void) { return 101; }
+extern "C" int64_t gsdd_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int64_t)sizeof(gsdd_gemm_desc);
+        case 1: return (int64_t)sizeof(gsdd_layer_desc);
+        case 2: return (int64_t)sizeof(gsdd_step_desc);
+        case 3: return (int64_t)sizeof(gsdd_train_desc);
+        default: return -1;
+    }
+}
 
 // ---------------------------------------------------------------- hipGraph capture
 extern "C" int gsdd_graph_begin(void* stream) {

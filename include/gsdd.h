@@ -32,6 +32,10 @@ extern "C" {
 
 const char* gsdd_last_error(void);
 int gsdd_version(void);
+/* sizeof of a descriptor struct as this build of the library sees it (which: 0 gsdd_gemm_desc, 1 gsdd_layer_desc, 2 gsdd_step_desc,
+ * 3 gsdd_train_desc; anything else: -1).  A binding checks its own struct sizes against these when it loads the library, so that a
+ * library built from another revision of this header fails at load time instead of misreading a descriptor. */
+int64_t gsdd_abi_sizeof(int which);
 
 /* ------------------------------------------------------------------ generic implicit GEMM
  * out[orow(m)][n] = epi( sum_{tap,c} pro(in[src(m,tap)][c]) * w[tap][n][c] )
