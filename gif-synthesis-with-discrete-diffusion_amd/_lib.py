@@ -17,7 +17,7 @@ EXPORTS = [
     "gsdd_relu_mask", "gsdd_lincomb", "gsdd_axial_attention_bwd", "gsdd_d3pm_embed", "gsdd_adaln_table", "gsdd_small_linear",
     "gsdd_d3pm_attention", "gsdd_d3pm_attention_workspace_bytes", "gsdd_d3pm_layer", "gsdd_d3pm_layer_pack", "gsdd_d3pm_layer_pack_h2", "gsdd_rows_linear_pack_many", "gsdd_rows_linear", "gsdd_d3pm_logits", "gsdd_d3pm_cross_attention", "gsdd_d3pm_step", "gsdd_d3pm_q_sample", "gsdd_d3pm_train_loss", "gsdd_d3pm_train_loss_bwd", "gsdd_d3pm_train_loss_grad", "gsdd_gelu2", "gsdd_ln_fwd", "gsdd_ln_bwd", "gsdd_wgrad",
     "gsdd_batch_rowsum", "gsdd_colsum", "gsdd_d3pm_attention_train", "gsdd_d3pm_attention_bwd", "gsdd_d3pm_attention_bwd_workspace_bytes", "gsdd_d3pm_embed_bwd", "gsdd_small_linear_bwd",
-    "gsdd_adaln_bwd", "gsdd_adam", "gsdd_adam_multi", "gsdd_advance",
+    "gsdd_adaln_bwd", "gsdd_adam", "gsdd_adam_multi", "gsdd_adam_multi_dev", "gsdd_advance",
     "gsdd_philox_uniform", "gsdd_graph_begin", "gsdd_graph_end", "gsdd_graph_launch", "gsdd_graph_destroy",
     "gsdd_event_create", "gsdd_event_record", "gsdd_event_elapsed_ms", "gsdd_event_destroy",
 ]
@@ -75,7 +75,7 @@ GEMM_EXACT_F32 = 1
 AXIAL_AUTO, AXIAL_VALU = 0, 1
 ATTN_AUTO, ATTN_P22, ATTN_P11, ATTN_A8, ATTN_A12, ATTN_F32PV, ATTN_KC256 = range(7)
 LAYER_AUTO, LAYER_X3P, LAYER_H2 = 0, 2, 3
-ATTN_BWD_AUTO, ATTN_BWD_VALU, ATTN_BWD_SPLIT, ATTN_BWD_FQC64, ATTN_BWD_FQC128, ATTN_BWD_NW8, ATTN_BWD_DBG1, ATTN_BWD_DBG2 = range(8)
+ATTN_BWD_AUTO, ATTN_BWD_VALU, ATTN_BWD_SPLIT, ATTN_BWD_FQC64, ATTN_BWD_FQC128, ATTN_BWD_NW8, ATTN_BWD_DBG1, ATTN_BWD_DBG2, ATTN_BWD_ATOMIC = range(9)
 
 
 class GsddError(RuntimeError):
@@ -154,6 +154,7 @@ def lib():
         L.gsdd_adaln_bwd.argtypes = [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p]
         L.gsdd_adam.argtypes = [_p, _p, _p, _p, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]
         L.gsdd_adam_multi.argtypes = [_p, _i, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]
+        L.gsdd_adam_multi_dev.argtypes = [_p, _i, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]
         L.gsdd_advance.argtypes = [_p, _i, _i64, _p, _i64, _p]
         L.gsdd_philox_uniform.argtypes = [C.c_uint64, _i64, _i64, _i64, _i, _p, _p]
         L.gsdd_graph_begin.argtypes = [_p]

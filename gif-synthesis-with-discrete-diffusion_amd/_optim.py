@@ -81,7 +81,9 @@ class MultiAdam:
             rows.append(t)
         return np.concatenate(rows)
 
-    def step(self, grads, stream=None):
+    def step(self, grads, stream=None, step_dev=None):
+        """step_dev: int64[1] device tensor holding the step count of THIS update (>= 1): the launch then bakes nothing that changes
+        from step to step (captured training step); the host-side count still advances so that checkpoints see it."""
         for name, p in self.params:
             g = grads[name]
             if not g.is_contiguous() or g.shape != p.shape:
@@ -91,5 +93,9 @@ class MultiAdam:
             self._table = torch.from_numpy(self._build_table(grads)).to(self.params[0][1].device)
             self._key = key
         self.step_count += 1
+        if step_dev is not None:
+            check(lib().gsdd_adam_multi_dev(ptr(self._table), self._table.shape[0], self.lr, self.betas[0], self.betas[1], self.eps,
+                                            ptr(step_dev), stream_ptr(stream)))
+            return
         check(lib().gsdd_adam_multi(ptr(self._table), self._table.shape[0], self.lr, self.betas[0], self.betas[1], self.eps,
                                     self.step_count, stream_ptr(stream)))

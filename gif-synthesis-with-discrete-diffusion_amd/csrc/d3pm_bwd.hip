@@ -523,9 +523,40 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const int64_t* __restri
     }
 }
 
+// the same with the step count in device memory (a captured training step is replayed: nothing of the update may be baked into the
+// launch): the bias corrections 1 - beta^step are evaluated per workgroup, in double (two pow calls per 4096 elements)
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const int64_t* __restrict__ table, float lr, float b1, float b2, float eps,
+                                                             const int64_t* __restrict__ step_dev) {
+    const double st = (double)step_dev[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, st)), bc2 = (float)(1.0 - pow((double)b2, st));
+    const int64_t* e = table + (int64_t)blockIdx.x * 5;
+    float* p = reinterpret_cast<float*>(e[0]);
+    const float* g = reinterpret_cast<const float*>(e[1]);
+    float* m = reinterpret_cast<float*>(e[2]);
+    float* v = reinterpret_cast<float*>(e[3]);
+    const int n = (int)e[4];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
 }  // namespace gsdd
 
 using namespace gsdd;
+
+extern "C" int gsdd_adam_multi_dev(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps,
+                                   const int64_t* step_dev, void* stream) {
+    GSDD_CHECK_ARG(table != nullptr && n_blocks > 0 && step_dev != nullptr, "bad args");
+    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, table, lr, beta1, beta2, eps,
+                       step_dev);
+    GSDD_CHECK_LAUNCH();
+    return GSDD_OK;
+}
 
 extern "C" int gsdd_adam_multi(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, int step,
                                void* stream) {

@@ -161,8 +161,6 @@ class Text2ImageTransformer(nn.Module):
             lay = dict(
                 ada1=ops.adaln_table(blk.ln1.emb.weight.contiguous(), blk.ln1.linear.weight.contiguous(),
                                      blk.ln1.linear.bias.contiguous()),
-                ada2=ops.adaln_table(blk.ln1_1.emb.weight.contiguous(), blk.ln1_1.linear.weight.contiguous(),
-                                     blk.ln1_1.linear.bias.contiguous()),
                 wqkv=torch.cat([a1.query.weight, a1.key.weight, a1.value.weight], 0).contiguous(),
                 bqkv=torch.cat([a1.query.bias, a1.key.bias, a1.value.bias], 0).contiguous(),
                 wproj=a1.proj.weight.contiguous(), bproj=a1.proj.bias.contiguous(),
@@ -177,6 +175,18 @@ class Text2ImageTransformer(nn.Module):
         p["gf"], p["bf"] = self.to_logits[0].weight.contiguous(), self.to_logits[0].bias.contiguous()
         p["wl"], p["bl"] = self.to_logits[1].weight.contiguous(), self.to_logits[1].bias.contiguous()
         return p
+
+    def _ada2(self, li):
+        """AdaLN table of block li's cross-attention norm (ln1_1).  Only the general path (more than one condition token) reads it --
+        with one token the cross-attention collapses to a vector and ln1_1 drops out -- so it is made on first use, not at every re-pack
+        (the training step re-packs after every update)."""
+        lay = self.packed()["layers"][li]
+        if "ada2" not in lay:
+            blk = self.blocks[li]
+            with torch.no_grad():
+                lay["ada2"] = ops.adaln_table(blk.ln1_1.emb.weight.contiguous(), blk.ln1_1.linear.weight.contiguous(),
+                                              blk.ln1_1.linear.bias.contiguous())
+        return lay["ada2"]
 
     def fragment_images(self, stream=None):
         """Weight fragment images of the fused layer kernel, made on the sampler's first use after the weights changed (the training
@@ -332,8 +342,9 @@ class Text2ImageTransformer(nn.Module):
                 ops.linear(y, lay["wproj"], x, bias=lay["bproj"], residual=x, stream=stream)
                 ops.row_stats(x, stats, stream=stream)
                 q2 = qkv[0:H]
+                ada2 = self._ada2(li)
                 ops.linear(x, lay["wq2"], q2, bias=lay["bq2"],
-                           ln=(stats, lay["ada2"].view(-1), lay["ada2"].view(-1)[D:], t2, 2 * D),
+                           ln=(stats, ada2.view(-1), ada2.view(-1)[D:], t2, 2 * D),
                            rows_per_batch=L, out_mode=2, stream=stream)
                 ops.d3pm_cross_attention(q2, condv[li][0], condv[li][1], B2, L, Te, H, y, stream=stream)
                 ops.linear(y, lay["wproj2"], x, bias=lay["bproj2"], residual=x, stream=stream)

@@ -156,11 +156,13 @@ class D3PMTrainer:
 
     # ------------------------------------------------------------------ loss + gradients
     @torch.no_grad()
-    def loss_and_grads(self, x0, cond, t=None, pt=None, want_probs=False, reduce=False):
+    def loss_and_grads(self, x0, cond, t=None, pt=None, want_probs=False, reduce=False, sid=None):
         """-> (loss tensor [1], {state_dict name: gradient}) for the transformer's parameters.  The gradients are views of one
         arena that the next call re-uses; `self.last_fwd` keeps the forward's dict (x0_recon, per_sample, probs if asked).
         reduce=True: the gradients come back averaged over the data-parallel group; the all-reduce runs in buckets of
-        BUCKET_LAYERS blocks issued while the backward of the earlier blocks is still being enqueued."""
+        BUCKET_LAYERS blocks issued while the backward of the earlier blocks is still being enqueued.
+        sid: int64[1] device tensor holding the Philox stream id of this step's q_sample draw (the captured step keeps it on the device);
+        None: made from dm.noise_stream."""
         self._sync_start()
         dm, tr = self.dm, self.dm.transformer
         if not x0.is_cuda:
@@ -174,7 +176,8 @@ class D3PMTrainer:
         if t is None:
             t, pt = dm.sample_time(B, dev, "importance")
         t, pt = t.to(dev).long().contiguous(), pt.to(dev).float().contiguous()
-        sid = torch.tensor([dm.noise_stream], dtype=torch.int64, device=dev)
+        if sid is None:
+            sid = torch.tensor([dm.noise_stream], dtype=torch.int64, device=dev)
         dm.noise_stream += 1
         sched = dm._sched()
         x0 = x0.contiguous().long()
@@ -293,8 +296,96 @@ class D3PMTrainer:
         return fwd["loss"], g
 
     # ------------------------------------------------------------------ optimiser step (Adam) with DP averaging
+    # ------------------------------------------------------------------ timestep sampling without a host synchronisation
+    def _sample_time_async(self, B, dev):
+        """DiffusionTransformer.sample_time(method='importance') (diffusion_transformer.py:368-389) without reading device memory:
+        the reference switches from uniform to importance sampling once every Lt_count exceeds 10, and Lt_count only ever grows by one
+        per sampled timestep (:432-436), so a host mirror of the counts decides the switch.  Uniform phase: t is drawn on the host (and
+        counted); importance phase (permanent once entered): t ~ multinomial(sqrt(Lt_history)) drawn on the device.  -> (t, pt) tensors."""
+        dm = self.dm
+        T = dm.num_timesteps
+        if getattr(self, "_lt_count_host", None) is None:
+            self._lt_count_host = dm.Lt_count.detach().cpu().numpy().astype("int64").copy()      # one read, at the first step
+        if (self._lt_count_host > 10).all():
+            Lt_sqrt = torch.sqrt(dm.Lt_history + 1e-10) + 0.0001
+            Lt_sqrt = torch.cat([Lt_sqrt[1:2], Lt_sqrt[1:]])                                      # Lt_sqrt[0] = Lt_sqrt[1] (:373)
+            pt_all = Lt_sqrt / Lt_sqrt.sum()
+            t = torch.multinomial(pt_all, num_samples=B, replacement=True)
+            return t, pt_all.gather(dim=0, index=t)
+        t = torch.randint(0, T, (B,))
+        import numpy as np
+        self._lt_count_host += np.bincount(t.numpy(), minlength=T)
+        return t.to(dev, non_blocking=True), torch.full((B,), 1.0 / T, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ the step as one captured graph
+    def _graph_usable(self, x0, cond):
+        return (os.environ.get("GSDD_TRAIN_GRAPH", "1") != "0" and x0.is_cuda and not self.reducer.active() and world_size() == 1
+                and cond.shape[1] == 1 and x0.shape[1] % 32 == 0)
+
+    def _capture(self, x0, cond):
+        """Everything of a step that runs on the device -- re-pack of the weight images and AdaLN tables, q_sample, forward, loss +
+        gradient, backward, Adam -- recorded once into a hipGraph and replayed: ~1000 small dependent launches leave ~2 ms of gaps per
+        step when they are enqueued one by one.  Nothing step-dependent is baked in: x_0, condition, t, p(t) live in static buffers,
+        the Philox stream id and Adam's step count are device words advanced inside the graph (gsdd_advance).  torch's graph-private
+        allocator pool keeps every activation of the captured step at its address (torch.cuda.graph is the plumbing; every node of
+        the graph is a libgsdd kernel or a fill / copy)."""
+        dm, dev = self.dm, x0.device
+        B = x0.shape[0]
+        st = {"shape": (tuple(x0.shape), tuple(cond.shape)), "lr": self.lr,
+              "x0": x0.clone().long().contiguous(), "cond": cond.clone().float().contiguous(),
+              "t": torch.zeros((B,), dtype=torch.int64, device=dev), "pt": torch.full((B,), 1.0 / dm.num_timesteps, dtype=torch.float32, device=dev),
+              "sid": torch.tensor([dm.noise_stream], dtype=torch.int64, device=dev),
+              "adam_step": torch.tensor([self._adam.step_count + 1], dtype=torch.int64, device=dev)}
+        tr = dm.transformer
+        keep = (dm.noise_stream, self._adam.step_count)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            tr._packed = None                                    # the re-pack is part of the graph: every replay sees the current weights
+            loss, grads = self.loss_and_grads(st["x0"], st["cond"], st["t"], st["pt"], reduce=False, sid=st["sid"])
+            self._adam.lr = self.lr
+            self._adam.step(grads, step_dev=st["adam_step"])
+            ops.advance(st["adam_step"], 1, st["sid"], 1)
+        dm.noise_stream, self._adam.step_count = keep             # capture executed nothing
+        st["graph"], st["loss"], st["packed"] = graph, loss, tr._packed
+        tr._packed = None
+        return st
+
     @torch.no_grad()
     def step(self, x0, cond, t=None, pt=None):
+        self._sync_start()
+        if self._graph_usable(x0, cond):
+            return self._step_graphed(x0, cond, t, pt)
+        return self._step_eager(x0, cond, t, pt)
+
+    def _step_graphed(self, x0, cond, t, pt):
+        """Two eager steps first (arenas, images and tables reach their final addresses), then capture, then replays."""
+        self._eager_steps = getattr(self, "_eager_steps", 0)
+        st = getattr(self, "_graph", None)
+        if st is not None and (st["shape"] != (tuple(x0.shape), tuple(cond.shape)) or st["lr"] != self.lr):
+            st = self._graph = None                              # another batch shape or learning rate: capture again
+        if st is None and self._eager_steps < 2:
+            self._eager_steps += 1
+            return self._step_eager(x0, cond, t, pt, nosync_time=True)
+        dm = self.dm
+        if st is None:
+            st = self._graph = self._capture(x0, cond)
+        if t is None:
+            t, pt = self._sample_time_async(x0.shape[0], x0.device)
+        st["x0"].copy_(x0, non_blocking=True)
+        st["cond"].copy_(cond, non_blocking=True)
+        st["t"].copy_(t, non_blocking=True)
+        st["pt"].copy_(pt, non_blocking=True)
+        st["graph"].replay()
+        dm.noise_stream += 1
+        self._adam.step_count += 1
+        self.step_count += 1
+        dm.transformer._packed = None                            # the packed views any eager caller holds predate this update
+        self.last_fwd = None
+        return st["loss"].clone()
+
+    def _step_eager(self, x0, cond, t=None, pt=None, nosync_time=False):
+        if t is None and nosync_time:
+            t, pt = self._sample_time_async(x0.shape[0], x0.device)
         loss, grads = self.loss_and_grads(x0, cond, t, pt, reduce=True)
         tr = self.dm.transformer
         params = dict(tr.named_parameters())
@@ -315,6 +406,7 @@ class D3PMTrainer:
         return a.state() if a is not None else getattr(self, "_pending_adam", None)
 
     def load_optimizer_state(self, state):
+        self._graph = None                                      # the captured step holds Adam's step count on the device
         if state is None:
             return
         if getattr(self, "_adam", None) is not None:

@@ -396,7 +396,8 @@ int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H);
 #define GSDD_ATTN_BWD_NW8 5
 #define GSDD_ATTN_BWD_DBG1 6
 #define GSDD_ATTN_BWD_DBG2 7
-#define GSDD_ATTN_BWD_DEV_LAST 7
+#define GSDD_ATTN_BWD_ATOMIC 8      /* partial dQ added with float atomics instead of the partial buffer + reduction kernel */
+#define GSDD_ATTN_BWD_DEV_LAST 8
 int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
                             int B, int L, int H, float* dqkv, float* scratch, void* workspace, int64_t workspace_bytes,
                             int variant, void* stream);
@@ -415,6 +416,10 @@ int gsdd_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 /* The same update over many tensors in one launch: table[b] = {p, g, m, v, n} (device pointers as int64, n <= 4096 elements) for
  * block b; the caller chops every parameter into such chunks. */
 int gsdd_adam_multi(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* ... with the step count (>= 1) read from device memory at execution time: the form a captured, replayed training step uses (the
+ * caller advances *step_dev with gsdd_advance inside the same graph). */
+int gsdd_adam_multi_dev(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, const int64_t* step_dev,
+                        void* stream);
 
 /* t[b] += dt ; stream[0] += ds   (device-side loop counters for the captured step graph) */
 int gsdd_advance(int64_t* t_dev, int B, int64_t dt, int64_t* stream_dev, int64_t ds, void* stream);

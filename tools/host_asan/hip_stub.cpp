@@ -51,6 +51,9 @@ hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int value) {
     return value <= 160 * 1024 ? hipSuccess : hipErrorInvalidValue;
 }
 hipError_t hipMemsetAsync(void* p, int, size_t, hipStream_t) { return p != nullptr ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipMemset2DAsync(void* p, size_t pitch, int, size_t width, size_t height, hipStream_t) {
+    return (p != nullptr && width <= pitch && height > 0) ? hipSuccess : hipErrorInvalidValue;
+}
 hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t) { return hipSuccess; }
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { if (g_capturing) return hipErrorIllegalState; g_capturing = 1; return hipSuccess; }
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {

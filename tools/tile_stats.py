@@ -42,6 +42,33 @@ def main():
             tile = rel.reshape(H, nq // 16, 16, L // 32, 32).amax(dim=(2, 4))        # max over the tile
             for pm in fr:
                 fr[pm] = float((tile > -pm).double().mean())
+            # what an A PRIORI bound could clear (a tile is cleared for a 16-query sub-tile when the bound proves every probability
+            # of the tile below 2^-8 of the final row sum for all 16 queries; Jensen: log2 rowsum >= log2 L + q'.kbar; budget = log2 L - 8):
+            #   A  the shipped form: ||q'|| max_tile ||k|| - q'.kbar < budget
+            #   B  keys centred on the head's mean key: ||q'|| max_tile ||k - kbar|| < budget
+            #   C  keys centred on their tile's mean c_u: q'.(c_u - kbar) + ||q'|| max_tile ||k - c_u|| < budget
+            #   H  per head (one launch-time flag): max_q ||q'|| max_k ||k - kbar|| < budget
+            #   T  the truth with the EXACT row sum (what no bound can beat): tile maximum of log2(p / rowsum) < -8
+            import math
+            qs = q[:, :nq] * (0.5 * 1.4426950408889634)                          # q' [H][nq][4]
+            kbar = k.mean(dim=1, keepdim=True)                                  # [H][1][4]
+            budget = math.log2(L) - 8.0
+            qn_ = qs.norm(dim=-1)                                                # [H][nq]
+            kt = k.reshape(H, L // 32, 32, 4)
+            kn_t = kt.norm(dim=-1).amax(dim=-1)                                  # [H][tiles]
+            kc_t = (kt - kbar[:, :, None, :]).norm(dim=-1).amax(dim=-1)
+            cu = kt.mean(dim=2)                                                  # [H][tiles][4]
+            ru = (kt - cu[:, :, None, :]).norm(dim=-1).amax(dim=-1)
+            qk = (qs * kbar).sum(-1)                                             # q'.kbar [H][nq]
+            bA = qn_[:, :, None] * kn_t[:, None, :] - qk[:, :, None]
+            bB = qn_[:, :, None] * kc_t[:, None, :]
+            bC = torch.einsum("hqd,hud->hqu", qs, cu - kbar) + qn_[:, :, None] * ru[:, None, :]
+            sub = lambda z: z.reshape(H, nq // 16, 16, -1).amax(dim=2)           # worst query of the sub-tile
+            clr = {n_: float((sub(z) < budget).double().mean()) for n_, z in (("A", bA), ("B", bB), ("C", bC))}
+            clr["H"] = float(((qn_.amax(dim=1) * (k - kbar).norm(dim=-1).amax(dim=1)) < budget).double().mean())
+            clr["T"] = float((tile <= -8).double().mean())
+            print(f"{regime:12s} layer {li:2d}: (sub-tile, tile) pairs cleared a priori: shipped bound {clr['A']:.3f}, keys centred on the head mean "
+                  f"{clr['B']:.3f}, on the tile mean {clr['C']:.3f}; whole heads {clr['H']:.3f}; truth {clr['T']:.3f}", flush=True)
             qn, kn = q.norm(dim=-1), k.norm(dim=-1)
             print(f"{regime:12s} layer {li:2d}: |q| mean {float(qn.mean()):.2f} max {float(qn.max()):.2f}  |k| mean {float(kn.mean()):.2f} max "
                   f"{float(kn.max()):.2f}  score std {float((s * 0.693).std()):.2f}  tiles with p > 2^-6 / 2^-8 / 2^-10 of the row sum: "
