@@ -75,7 +75,7 @@ GEMM_EXACT_F32 = 1
 AXIAL_AUTO, AXIAL_VALU = 0, 1
 ATTN_AUTO, ATTN_P22, ATTN_P11, ATTN_A8, ATTN_A12, ATTN_F32PV, ATTN_KC256 = range(7)
 LAYER_AUTO, LAYER_X3P, LAYER_H2 = 0, 2, 3
-ATTN_BWD_AUTO, ATTN_BWD_VALU, ATTN_BWD_SPLIT, ATTN_BWD_FQC64, ATTN_BWD_FQC128, ATTN_BWD_NW8, ATTN_BWD_DBG1, ATTN_BWD_DBG2, ATTN_BWD_ATOMIC = range(9)
+ATTN_BWD_AUTO, ATTN_BWD_VALU, ATTN_BWD_SPLIT, ATTN_BWD_FQC64, ATTN_BWD_FQC128, ATTN_BWD_NW8, ATTN_BWD_DBG1, ATTN_BWD_DBG2 = range(8)
 
 
 class GsddError(RuntimeError):

@@ -529,9 +529,10 @@ __device__ __forceinline__ uint2 lds_read_tr16(const uint2* p) {
     const bw_v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bw_v4s*)(p));
     return __builtin_bit_cast(uint2, r);
 }
-// ATOMIC: the partial dQ of a (query chunk, 256-key block) is added straight into dqkv with float atomics (no partial buffer, no
-// reduction kernel; dqkv's dQ columns must be zero at launch) -- summation order, hence the last bits of dQ, then vary from run to run
-template <int DBG, int NW = 4, int FQ = 128, bool ATOMIC = false>   // DBG 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing only)
+// (Adding the partial dQ of a (query chunk, 256-key block) straight into dqkv with float atomics -- no partial buffer, no reduction
+// kernel -- was built and measured in round 4: 2.33 ms against 1.84 ms for this kernel + the reduction at B = 16, L = 4096: 67 M
+// atomics per layer cost more than the 268 MB of plain stores and the 50 us reduction they replace.)
+template <int DBG, int NW = 4, int FQ = 128>   // DBG 0: the kernel; 1: without the LDS hand-over of dQ; 2: without the dQ product as well (timing only)
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float* __restrict__ k, const float* __restrict__ v, BwdImages im,
                                                                     int B, int L, int H, float* __restrict__ dqkv,
                                                                     float* __restrict__ dq_part) {
@@ -613,14 +614,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const float*
                 s0 += sm.dq[ch & 1][w][c0][q];
                 s1 += sm.dq[ch & 1][w][c0 + 1][q];
             }
-            if (ATOMIC) {
-                float* dst = dqkv + ((int64_t)b * L + qi) * (3 * H * 4) + h * 4 + c0;
-                atomicAdd(dst, 0.5f * s0);
-                atomicAdd(dst + 1, 0.5f * s1);
-            } else {
-                *reinterpret_cast<float2*>(dq_part + (((int64_t)kblk * H + h) * M + (int64_t)b * L + qi) * 4 + c0) =
-                    make_float2(0.5f * s0, 0.5f * s1);
-            }
+            *reinterpret_cast<float2*>(dq_part + (((int64_t)kblk * H + h) * M + (int64_t)b * L + qi) * 4 + c0) =
+                make_float2(0.5f * s0, 0.5f * s1);
         }
     };
 
@@ -807,8 +802,6 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
                                                (int)sizeof(FusedSmem<4, 64>)));
             GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)sizeof(FusedSmem<4, 96>)));
-            GSDD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<0, 4, 96, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)sizeof(FusedSmem<4, 96>)));
         );
         // development variants (include/gsdd.h): debug stages of the fused kernel, queries per LDS chunk 96 (default) / 64 / 128, waves per
         // workgroup 4 (default) or 8
@@ -817,13 +810,6 @@ int gsdd_attention_bwd_mfma(const float* q, const float* k, const float* v, cons
         const int nw = variant == GSDD_ATTN_BWD_NW8 ? 8 : 4;
         const int kb = 64 * nw, nkb = (L + kb - 1) / kb;
         const dim3 fgrid((unsigned)(B * H * nkb));
-        if (variant == GSDD_ATTN_BWD_ATOMIC) {
-            GSDD_CHECK_HIP(hipMemset2DAsync(dqkv, (size_t)3 * H * 4 * sizeof(float), 0, (size_t)H * 4 * sizeof(float), (size_t)M, st));
-            hipLaunchKernelGGL((attn_bwd_fused_kernel<0, 4, 96, true>), fgrid, dim3(256), sizeof(FusedSmem<4, 96>), st, k, v, im, B, L, H, dqkv, dq_part);
-            GSDD_CHECK_LAUNCH();
-            *done = 1;
-            return GSDD_OK;
-        }
         if (dbgv == 1) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
         else if (dbgv == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<2, 4>), fgrid, dim3(256), sizeof(FusedSmem<4, 128>), st, k, v, im, B, L, H, dqkv, dq_part);
         else if (nw == 4 && fqc == 64)

@@ -792,8 +792,21 @@ class DiscreteDiffusion(nn.Module):
         # the two decodes nobody may ever read (LazyOutputs): deferred while the VQ-VAE is frozen in eval mode (a train-mode decode
         # would update BatchNorm statistics: then it happens here, as in the reference); GSDD_EAGER_OUTPUTS=1 computes them here too
         lazy = (not autoencoder.training) and os.environ.get("GSDD_EAGER_OUTPUTS") is None
-        single_step_out = Deferred(lambda: autoencoder.decode(pred_tokens))
-        test = Deferred(lambda: autoencoder.decode(quant))
+        # a deferred decode must be the decode the eager call would have made: it is refused if the VQ-VAE's weights have been replaced or
+        # updated (through torch) since this forward (the reference decodes here, under the weights of this moment)
+        weights_now = lambda: tuple((p.data_ptr(), p._version) for p in autoencoder.parameters())
+        weights_then = weights_now() if lazy else None
+
+        def deferred_decode(tokens):
+            def fn():
+                if weights_now() != weights_then:
+                    raise GsddError("the VQ-VAE's weights changed between DiscreteDiffusion.forward and the first read of a deferred output "
+                                    "(pred_data / pred_single_step / test): read it before updating the autoencoder, or set "
+                                    "GSDD_EAGER_OUTPUTS=1 to decode inside forward as the reference does")
+                return autoencoder.decode(tokens)
+            return Deferred(fn)
+        single_step_out = deferred_decode(pred_tokens)
+        test = deferred_decode(quant)
         with torch.no_grad():
             if do_inference:                # (the sampler draws from the noise stream: always at this point of the call)
                 inference_out = self.sample_videos(batch["text"], autoencoder, latent_shape=tuple(quant.shape[1:]),

@@ -19,7 +19,7 @@ _ATTN_MODES = {"auto": abi.ATTN_AUTO, "22": abi.ATTN_P22, "11": abi.ATTN_P11, "a
                "f32pv": abi.ATTN_F32PV, "kc256": abi.ATTN_KC256}
 _LAYER_VARIANTS = {"auto": abi.LAYER_AUTO, "h2": abi.LAYER_H2, "x3p": abi.LAYER_X3P}
 _ATTN_BWD_VARIANTS = {"auto": abi.ATTN_BWD_AUTO, "valu": abi.ATTN_BWD_VALU, "split": abi.ATTN_BWD_SPLIT, "fqc64": abi.ATTN_BWD_FQC64,
-                      "fqc128": abi.ATTN_BWD_FQC128, "nw8": abi.ATTN_BWD_NW8, "dbg1": abi.ATTN_BWD_DBG1, "dbg2": abi.ATTN_BWD_DBG2, "atomic": abi.ATTN_BWD_ATOMIC}
+                      "fqc128": abi.ATTN_BWD_FQC128, "nw8": abi.ATTN_BWD_NW8, "dbg1": abi.ATTN_BWD_DBG1, "dbg2": abi.ATTN_BWD_DBG2}
 
 
 def _pick(table, value, what):

@@ -396,8 +396,7 @@ int64_t gsdd_d3pm_attention_bwd_workspace_bytes(int B, int L, int H);
 #define GSDD_ATTN_BWD_NW8 5
 #define GSDD_ATTN_BWD_DBG1 6
 #define GSDD_ATTN_BWD_DBG2 7
-#define GSDD_ATTN_BWD_ATOMIC 8      /* partial dQ added with float atomics instead of the partial buffer + reduction kernel */
-#define GSDD_ATTN_BWD_DEV_LAST 8
+#define GSDD_ATTN_BWD_DEV_LAST 7
 int gsdd_d3pm_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO, const float* lse,
                             int B, int L, int H, float* dqkv, float* scratch, void* workspace, int64_t workspace_bytes,
                             int variant, void* stream);

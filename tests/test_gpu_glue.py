@@ -114,6 +114,13 @@ def test_generator_defers_unread_decodes(G, golden, monkeypatch):
     with torch.no_grad():
         assert gen(batch, vq, None).pending() == []
     vq.eval()
+    # a deferred decode is refused once the VQ-VAE's weights have moved (it would no longer be the decode of this forward)
+    with torch.no_grad():
+        out = gen(batch, vq, None)
+        next(vq.parameters()).mul_(1.0)                  # an in-place update through torch bumps the version counter
+    with pytest.raises(G.GsddError):
+        out["test"]
+    _ = out["losses"], out["gt_data"]                    # what was computed inside forward stays readable
 
 
 def test_glue_loss_backward_fills_transformer_grads(G, golden):

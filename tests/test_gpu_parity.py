@@ -375,7 +375,8 @@ def test_d3pm_attention(G, B, L, spike, use_ws):
     assert err < 2e-5, err
 
 
-@pytest.mark.parametrize("case", ["flat", "hot_tile", "hot_query", "growing_norms", "zero_q", "mean_shift", "two_clusters", "unit_scale"])
+@pytest.mark.parametrize("case", ["flat", "hot_tile", "hot_query", "growing_norms", "zero_q", "mean_shift", "two_clusters", "unit_scale",
+                                  "common_mean", "common_mean_hot_tile", "common_mean_drift"])
 def test_attention_norm_bound(G, case, monkeypatch):
     """The adaptive mode's bounds (kernel note in d3pm_attention.hip): tiles whose ||q|| ||k|| bound keeps every probability below 2^-8
     of the row sum -- the row sum so far, or the lower bound of the final one from the mean key (Jensen) -- take the f16 hi half only,
@@ -403,6 +404,15 @@ def test_attention_norm_bound(G, case, monkeypatch):
         q = q * 6.0
     elif case == "unit_scale":      # structureless unit-scale q, k (trained-like spread): a quarter of the tiles hold a probability
         q, k = q / 0.15, k / 0.15                                 # above the threshold
+    elif case.startswith("common_mean"):
+        # the trained-like regime: keys = a large common vector + a small spread, queries of unit scale.  ||q'|| ||k|| is ~10 bits, so
+        # the norm bound proves nothing although no tile holds a large probability (||q'|| ||k - kmean|| ~1 bit): the measured test decides
+        k = k * 3.0 + torch.tensor([4.0, -3.0, 2.0, 1.0])
+        q = q * 12.0
+        if case == "common_mean_hot_tile":   # ... except one tile whose keys sit far from the mean along some queries: it must keep its lo half
+            k[:, :, 77 * 32:78 * 32] += q[:, :, 100:132] * 2.0
+        elif case == "common_mean_drift":    # ... and a mean that drifts along the row
+            k = k + torch.linspace(-1.5, 1.5, L).view(1, 1, L, 1) * torch.tensor([1.0, 0.5, -0.5, 0.25])
     want = attention_ref(q, k, v).permute(0, 2, 1, 3).reshape(B * L, H * 4)
     hm = lambda z: dev(z.permute(1, 0, 2, 3).reshape(H, B * L, 4).contiguous())
     outs = {}

@@ -181,8 +181,9 @@ def test_training_forward_attention_modes_agree_at_long_sequences(G, monkeypatch
     # the default IS a8 at this length: same loss bit for bit (the forward is deterministic); the gradients agree to the order of the
     # weight-gradient kernels' float atomics
     assert res[None][0] == res["a8"][0]
-    for k, w in res["a8"][1].items():
-        torch.testing.assert_close(res[None][1][k], w, atol=1e-6 * max(w.abs().max().item(), 1e-30), rtol=1e-5)
+    gmax8 = max(v.abs().max().item() for v in res["a8"][1].values())
+    for k, w in res["a8"][1].items():                # (mathematically zero gradients -- attn1.key.bias -- are rounding noise: absolute bar)
+        torch.testing.assert_close(res[None][1][k], w, atol=1e-6 * gmax8, rtol=1e-5)
     gmax = max(v.abs().max().item() for v in res["22"][1].values())
     worst = max(((res[None][1][k] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), k) for k, w in res["22"][1].items())
     parity_report("train_attention_default_vs_hi_lo_L2048", {"loss_default": res[None][0], "loss_hi_lo": res["22"][0],
@@ -219,6 +220,8 @@ def test_captured_training_step_equals_the_eager_steps(G, golden, monkeypatch):
     monkeypatch.delenv("GSDD_TRAIN_GRAPH")
     np.testing.assert_allclose(runs["1"][0], runs["0"][0], rtol=2e-5)
     for k, w in runs["0"][1].items():
+        if k.endswith("attn1.key.bias"):              # softmax is shift invariant: this gradient is mathematically zero, what arrives is
+            continue                                  # rounding noise in atomics order, and Adam normalises noise to full-size updates
         torch.testing.assert_close(runs["1"][1][k], w, atol=2e-6, rtol=1e-5, msg=lambda m, k=k: f"{k}: {m}")
     assert torch.equal(runs["1"][2], runs["0"][2])
     assert runs["1"][3]["step"] == runs["0"][3]["step"] == len(batches)
@@ -365,7 +368,7 @@ def test_rccl_initialises_and_carries_the_bucketed_exchange_on_one_gpu(G):
 
 
 # ----------------------------------------------------------------------------- attention backward kernels vs fp64 autograd
-@pytest.mark.parametrize("mode", ["fused", "fused_q64", "fused_q128", "fused_w8", "fused_atomic", "split", "valu"])
+@pytest.mark.parametrize("mode", ["fused", "fused_q64", "fused_q128", "fused_w8", "split", "valu"])
 @pytest.mark.parametrize("B,L,scale", [(2, 64, 1.0), (1, 320, 1.5), (1, 1024, 1.0), (2, 96, 3.0), (2, 544, 1.0)])
 def test_attention_backward_matches_fp64_autograd(G, B, L, scale, mode, monkeypatch):
     """dq | dk | dv of softmax(q k^T / 2) v for head dim 4 against torch.autograd in fp64: the fused matrix-pipe kernel (one pass,
@@ -373,7 +376,7 @@ def test_attention_backward_matches_fp64_autograd(G, B, L, scale, mode, monkeypa
     chunks and 8-wave workgroups), the two-kernel matrix-pipe variant (variant "split") and the VALU kernels (no workspace).
     L = 320 / 544 cover partial key blocks and query chunks (544 = 2 key blocks + 32, 5 query chunks + 64), scale 3 peaky attention."""
     valu = mode == "valu"
-    variant = {"fused": None, "fused_q64": "fqc64", "fused_q128": "fqc128", "fused_w8": "nw8", "fused_atomic": "atomic", "split": "split", "valu": "valu"}[mode]
+    variant = {"fused": None, "fused_q64": "fqc64", "fused_q128": "fqc128", "fused_w8": "nw8", "split": "split", "valu": "valu"}[mode]
     H = 16
     g = torch.Generator().manual_seed(9)
     q = (torch.randn(B, H, L, 4, generator=g) * scale).double().requires_grad_(True)

@@ -57,7 +57,7 @@ def main():
         ops.d3pm_attention_train(qkv[0:H], qkv[H:2 * H], qkv[2 * H:], Bt, L, H, o, lse, ws=ops.d3pm_attention_workspace(Bt, L, H, dev))
         ws = ops.d3pm_attention_bwd_workspace(Bt, L, H, dev)
         fl = 40.0 * L * L * H * Bt
-        variants = (("fused", None), ("fused no-LDS-acc", "dbg1"), ("fused no-dQ", "dbg2"), ("split", "split"), ("atomic dQ", "atomic"))
+        variants = (("fused", None), ("fused no-LDS-acc", "dbg1"), ("fused no-dQ", "dbg2"), ("split", "split"))
         if os.environ.get("GSDD_BENCH_BWD_VARIANTS"):      # e.g. "fused": the counter passes want the shipped variant alone
             keep = os.environ["GSDD_BENCH_BWD_VARIANTS"].split(",")
             variants = tuple(v for v in variants if v[0] in keep)

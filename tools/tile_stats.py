@@ -35,7 +35,7 @@ def main():
             qkv = sv["layers"][li]["qkv"]                       # [3H][M][4]
             q, k = qkv[0:H].double(), qkv[H:2 * H].double()
             fr = {8: 0.0, 6: 0.0, 10: 0.0}
-            nq = 512                                           # a sample of query rows per head
+            nq = int(os.environ.get("GSDD_TILE_STATS_NQ", "512"))            # a sample of query rows per head
             s = (q[:, :nq] @ k.transpose(1, 2)) * 0.5 * 1.4426950408889634          # log2 domain, [H][nq][L]
             lse = torch.logsumexp(s * 0.6931471805599453, dim=-1, keepdim=True) * 1.4426950408889634
             rel = s - lse                                       # log2(p / rowsum)
@@ -63,12 +63,39 @@ def main():
             bA = qn_[:, :, None] * kn_t[:, None, :] - qk[:, :, None]
             bB = qn_[:, :, None] * kc_t[:, None, :]
             bC = torch.einsum("hqd,hud->hqu", qs, cu - kbar) + qn_[:, :, None] * ru[:, None, :]
+            #   D  what a producer-side statistic would give: the tile's radius about an anchor a_u the producer knows (the mean of the
+            #      tile's first 16 keys) plus the anchor's distance from the mean key: ||q'|| (max_tile ||k - a_u|| + ||a_u - kbar||) < budget
+            au = kt[:, :, :16].mean(dim=2)
+            rau = (kt - au[:, :, None, :]).norm(dim=-1).amax(dim=-1)
+            bD = qn_[:, :, None] * (rau + (au - kbar).norm(dim=-1))[:, None, :]
             sub = lambda z: z.reshape(H, nq // 16, 16, -1).amax(dim=2)           # worst query of the sub-tile
-            clr = {n_: float((sub(z) < budget).double().mean()) for n_, z in (("A", bA), ("B", bB), ("C", bC))}
+            clr = {n_: float((sub(z) < budget).double().mean()) for n_, z in (("A", bA), ("B", bB), ("C", bC), ("D", bD))}
+            chunk = lambda z: float((sub(z).reshape(H, nq // 64, 4, -1)[..., :120].reshape(H, nq // 64, 4, 10, 12).amax(dim=(2, 4)) < budget).double().mean())
+            clr["Bchunk"], clr["Dchunk"] = chunk(bB), chunk(bD)
             clr["H"] = float(((qn_.amax(dim=1) * (k - kbar).norm(dim=-1).amax(dim=1)) < budget).double().mean())
             clr["T"] = float((tile <= -8).double().mean())
             print(f"{regime:12s} layer {li:2d}: (sub-tile, tile) pairs cleared a priori: shipped bound {clr['A']:.3f}, keys centred on the head mean "
-                  f"{clr['B']:.3f}, on the tile mean {clr['C']:.3f}; whole heads {clr['H']:.3f}; truth {clr['T']:.3f}", flush=True)
+                  f"{clr['B']:.3f}, on the tile mean {clr['C']:.3f}; whole heads {clr['H']:.3f}; truth {clr['T']:.3f}; producer-side radius {clr['D']:.3f}; "
+                  f"(wave, 384-key chunk) blocks cleared whole: head mean {clr['Bchunk']:.3f}, producer-side {clr['Dchunk']:.3f}", flush=True)
+            # the kernel itself on exactly these q, k, v: adaptive (a8) against hi only (11) and hi + lo (22) -- what the bounds buy
+            from gsdd_amd import ops
+            RB = 16                                            # the row replicated: a launch of the bench's size per lane
+            qf, kf, vf = (qkv[i * H:(i + 1) * H].repeat(1, RB, 1).contiguous() for i in range(3))
+            outb = torch.empty((RB * L, H * 4), device="cuda")
+            wsb = ops.d3pm_attention_workspace(RB, L, H, "cuda")
+            tms = {}
+            for mode in ("a8", "11", "22"):
+                for _ in range(3):
+                    ops.d3pm_attention(qf, kf, vf, RB, L, H, outb, ws=wsb, mode=mode)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    ops.d3pm_attention(qf, kf, vf, RB, L, H, outb, ws=wsb, mode=mode)
+                e1.record()
+                torch.cuda.synchronize()
+                tms[mode] = e0.elapsed_time(e1) / 20 * 1e3
+            print(f"{regime:12s} layer {li:2d}: kernel (the row x 16: prep + attention, us) adaptive {tms['a8']:.1f}  hi only {tms['11']:.1f}  hi + lo {tms['22']:.1f}", flush=True)
             qn, kn = q.norm(dim=-1), k.norm(dim=-1)
             print(f"{regime:12s} layer {li:2d}: |q| mean {float(qn.mean()):.2f} max {float(qn.max()):.2f}  |k| mean {float(kn.mean()):.2f} max "
                   f"{float(kn.max()):.2f}  score std {float((s * 0.693).std()):.2f}  tiles with p > 2^-6 / 2^-8 / 2^-10 of the row sum: "
