@@ -319,8 +319,10 @@ class D3PMTrainer:
 
     # ------------------------------------------------------------------ the step as one captured graph
     def _graph_usable(self, x0, cond):
-        return (os.environ.get("GSDD_TRAIN_GRAPH", "1") != "0" and x0.is_cuda and not self.reducer.active() and world_size() == 1
-                and cond.shape[1] == 1 and x0.shape[1] % 32 == 0)
+        """Single-process steps only: with a data-parallel group the bucketed all-reduces run between the backward's launches through
+        torch.distributed, outside any capture (the eager path; its launch gaps are covered by the collectives' own latency)."""
+        return (os.environ.get("GSDD_TRAIN_GRAPH", "1") != "0" and not getattr(self, "_graph_failed", False) and x0.is_cuda
+                and not self.reducer.active() and world_size() == 1 and cond.shape[1] == 1 and x0.shape[1] % 32 == 0)
 
     def _capture(self, x0, cond):
         """Everything of a step that runs on the device -- re-pack of the weight images and AdaLN tables, q_sample, forward, loss +
@@ -368,7 +370,17 @@ class D3PMTrainer:
             return self._step_eager(x0, cond, t, pt, nosync_time=True)
         dm = self.dm
         if st is None:
-            st = self._graph = self._capture(x0, cond)
+            keep = (dm.noise_stream, self._adam.step_count)
+            try:
+                st = self._graph = self._capture(x0, cond)
+            except Exception as e:                                # noqa: BLE001  (a capture that cannot be made must not cost the step)
+                import warnings
+                warnings.warn(f"D3PMTrainer: the training step could not be captured as a graph ({type(e).__name__}: {e}); running launch by launch")
+                dm.noise_stream, self._adam.step_count = keep
+                self._graph_failed = True
+                dm.transformer._packed = None
+                torch.cuda.synchronize()
+                return self._step_eager(x0, cond, t, pt, nosync_time=True)
         if t is None:
             t, pt = self._sample_time_async(x0.shape[0], x0.device)
         st["x0"].copy_(x0, non_blocking=True)
