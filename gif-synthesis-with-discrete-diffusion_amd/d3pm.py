@@ -799,7 +799,7 @@ class DiscreteDiffusion(nn.Module):
 
         def deferred_decode(tokens):
             def fn():
-                if weights_now() != weights_then:
+                if weights_then is not None and weights_now() != weights_then:
                     raise GsddError("the VQ-VAE's weights changed between DiscreteDiffusion.forward and the first read of a deferred output "
                                     "(pred_data / pred_single_step / test): read it before updating the autoencoder, or set "
                                     "GSDD_EAGER_OUTPUTS=1 to decode inside forward as the reference does")

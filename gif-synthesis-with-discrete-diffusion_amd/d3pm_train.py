@@ -296,27 +296,6 @@ class D3PMTrainer:
         return fwd["loss"], g
 
     # ------------------------------------------------------------------ optimiser step (Adam) with DP averaging
-    # ------------------------------------------------------------------ timestep sampling without a host synchronisation
-    def _sample_time_async(self, B, dev):
-        """DiffusionTransformer.sample_time(method='importance') (diffusion_transformer.py:368-389) without reading device memory:
-        the reference switches from uniform to importance sampling once every Lt_count exceeds 10, and Lt_count only ever grows by one
-        per sampled timestep (:432-436), so a host mirror of the counts decides the switch.  Uniform phase: t is drawn on the host (and
-        counted); importance phase (permanent once entered): t ~ multinomial(sqrt(Lt_history)) drawn on the device.  -> (t, pt) tensors."""
-        dm = self.dm
-        T = dm.num_timesteps
-        if getattr(self, "_lt_count_host", None) is None:
-            self._lt_count_host = dm.Lt_count.detach().cpu().numpy().astype("int64").copy()      # one read, at the first step
-        if (self._lt_count_host > 10).all():
-            Lt_sqrt = torch.sqrt(dm.Lt_history + 1e-10) + 0.0001
-            Lt_sqrt = torch.cat([Lt_sqrt[1:2], Lt_sqrt[1:]])                                      # Lt_sqrt[0] = Lt_sqrt[1] (:373)
-            pt_all = Lt_sqrt / Lt_sqrt.sum()
-            t = torch.multinomial(pt_all, num_samples=B, replacement=True)
-            return t, pt_all.gather(dim=0, index=t)
-        t = torch.randint(0, T, (B,))
-        import numpy as np
-        self._lt_count_host += np.bincount(t.numpy(), minlength=T)
-        return t.to(dev, non_blocking=True), torch.full((B,), 1.0 / T, dtype=torch.float32, device=dev)
-
     # ------------------------------------------------------------------ the step as one captured graph
     def _graph_usable(self, x0, cond):
         """Single-process steps only: with a data-parallel group the bucketed all-reduces run between the backward's launches through
@@ -328,7 +307,8 @@ class D3PMTrainer:
         """Everything of a step that runs on the device -- re-pack of the weight images and AdaLN tables, q_sample, forward, loss +
         gradient, backward, Adam -- recorded once into a hipGraph and replayed: ~1000 small dependent launches leave ~2 ms of gaps per
         step when they are enqueued one by one.  Nothing step-dependent is baked in: x_0, condition, t, p(t) live in static buffers,
-        the Philox stream id and Adam's step count are device words advanced inside the graph (gsdd_advance).  torch's graph-private
+        the Philox stream id and Adam's step count are device words advanced inside the graph (gsdd_advance); the timesteps are drawn
+        by DiffusionTransformer.sample_time before each replay, exactly as the eager step draws them.  torch's graph-private
         allocator pool keeps every activation of the captured step at its address (torch.cuda.graph is the plumbing; every node of
         the graph is a libgsdd kernel or a fill / copy)."""
         dm, dev = self.dm, x0.device
@@ -367,7 +347,7 @@ class D3PMTrainer:
             st = self._graph = None                              # another batch shape or learning rate: capture again
         if st is None and self._eager_steps < 2:
             self._eager_steps += 1
-            return self._step_eager(x0, cond, t, pt, nosync_time=True)
+            return self._step_eager(x0, cond, t, pt)
         dm = self.dm
         if st is None:
             keep = (dm.noise_stream, self._adam.step_count)
@@ -380,9 +360,11 @@ class D3PMTrainer:
                 self._graph_failed = True
                 dm.transformer._packed = None
                 torch.cuda.synchronize()
-                return self._step_eager(x0, cond, t, pt, nosync_time=True)
+                return self._step_eager(x0, cond, t, pt)
         if t is None:
-            t, pt = self._sample_time_async(x0.shape[0], x0.device)
+            # the reference's own timestep sampler (importance sampling once every Lt_count exceeds 10: its check reads device memory,
+            # i.e. waits for the previous step -- one host round trip per step, ~0.1 ms beside a 54 ms replay)
+            t, pt = dm.sample_time(x0.shape[0], x0.device, "importance")
         st["x0"].copy_(x0, non_blocking=True)
         st["cond"].copy_(cond, non_blocking=True)
         st["t"].copy_(t, non_blocking=True)
@@ -395,9 +377,7 @@ class D3PMTrainer:
         self.last_fwd = None
         return st["loss"].clone()
 
-    def _step_eager(self, x0, cond, t=None, pt=None, nosync_time=False):
-        if t is None and nosync_time:
-            t, pt = self._sample_time_async(x0.shape[0], x0.device)
+    def _step_eager(self, x0, cond, t=None, pt=None):
         loss, grads = self.loss_and_grads(x0, cond, t, pt, reduce=True)
         tr = self.dm.transformer
         params = dict(tr.named_parameters())

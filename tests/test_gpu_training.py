@@ -225,7 +225,8 @@ def test_captured_training_step_equals_the_eager_steps(G, golden, monkeypatch):
         torch.testing.assert_close(runs["1"][1][k], w, atol=2e-6, rtol=1e-5, msg=lambda m, k=k: f"{k}: {m}")
     assert torch.equal(runs["1"][2], runs["0"][2])
     assert runs["1"][3]["step"] == runs["0"][3]["step"] == len(batches)
-    torch.testing.assert_close(runs["1"][3]["m"], runs["0"][3]["m"], atol=1e-7, rtol=1e-4)
+    m0 = runs["0"][3]["m"]                           # (entries fed by mathematically zero gradients hold atomics-order noise: absolute bar)
+    torch.testing.assert_close(runs["1"][3]["m"], m0, atol=1e-5 * m0.abs().max().item(), rtol=1e-4)
 
 
 def test_adam_step_matches_torch(G, golden):
