@@ -307,7 +307,7 @@ class D3PMTrainer:
         """Everything of a step that runs on the device -- re-pack of the weight images and AdaLN tables, q_sample, forward, loss +
         gradient, backward, Adam -- recorded once into a hipGraph and replayed: ~1000 small dependent launches leave ~2 ms of gaps per
         step when they are enqueued one by one.  Nothing step-dependent is baked in: x_0, condition, t, p(t) live in static buffers,
-        the Philox stream id and Adam's step count are device words advanced inside the graph (gsdd_advance); the timesteps are drawn
+        the Philox stream id and Adam's step count are device words the host sets before each replay; the timesteps are drawn
         by DiffusionTransformer.sample_time before each replay, exactly as the eager step draws them.  torch's graph-private
         allocator pool keeps every activation of the captured step at its address (torch.cuda.graph is the plumbing; every node of
         the graph is a libgsdd kernel or a fill / copy)."""
@@ -326,7 +326,6 @@ class D3PMTrainer:
             loss, grads = self.loss_and_grads(st["x0"], st["cond"], st["t"], st["pt"], reduce=False, sid=st["sid"])
             self._adam.lr = self.lr
             self._adam.step(grads, step_dev=st["adam_step"])
-            ops.advance(st["adam_step"], 1, st["sid"], 1)
         dm.noise_stream, self._adam.step_count = keep             # capture executed nothing
         st["graph"], st["loss"], st["packed"] = graph, loss, tr._packed
         tr._packed = None
@@ -369,6 +368,11 @@ class D3PMTrainer:
         st["cond"].copy_(cond, non_blocking=True)
         st["t"].copy_(t, non_blocking=True)
         st["pt"].copy_(pt, non_blocking=True)
+        # the two device words are set from the host's counts before every replay (two fills): whoever else draws from the noise stream
+        # between steps -- the validation loop's _train_loss, set_noise, a resumed checkpoint -- moves dm.noise_stream, and the replay
+        # must use the stream id the eager step would
+        st["sid"].fill_(dm.noise_stream)
+        st["adam_step"].fill_(self._adam.step_count + 1)
         st["graph"].replay()
         dm.noise_stream += 1
         self._adam.step_count += 1

@@ -198,7 +198,7 @@ def test_training_forward_attention_modes_agree_at_long_sequences(G, monkeypatch
 
 def test_captured_training_step_equals_the_eager_steps(G, golden, monkeypatch):
     """D3PMTrainer.step replays one captured hipGraph from its third step on (re-pack, q_sample, forward, loss + gradient, backward,
-    Adam; the Philox stream id and Adam's step count are device words advanced inside the graph).  Seven steps on changing batches and
+    Adam; the Philox stream id and Adam's step count are device words set before each replay).  Seven steps on changing batches and
     timesteps must give the losses and the weights of the eager trainer (GSDD_TRAIN_GRAPH=0): nothing step-dependent may be baked in.
     (Adam's bias corrections are evaluated in double on the device and in float on the host: the weights agree to 1e-6.)"""
     from gsdd_amd.d3pm_train import D3PMTrainer
@@ -213,9 +213,13 @@ def test_captured_training_step_equals_the_eager_steps(G, golden, monkeypatch):
         dm = build(G, sd, cfg).train()
         dm.set_noise(cfg["noise_seed"], stream=3)
         tr = D3PMTrainer(dm, lr=1e-3)
-        losses = [tr.step(x0, cond, t=t, pt=pt)[0].item() for x0, cond, t, pt in batches]
+        losses = []
+        for i, (x0, cond, t, pt) in enumerate(batches):
+            if i == 4:                                # somebody else draws from the noise stream between two steps (a validation pass does)
+                dm.noise_stream += 3
+            losses.append(tr.step(x0, cond, t=t, pt=pt)[0].item())
         assert (getattr(tr, "_graph", None) is not None) == (mode == "1")
-        assert dm.noise_stream == 3 + len(batches) and tr._adam.step_count == len(batches)
+        assert dm.noise_stream == 3 + 3 + len(batches) and tr._adam.step_count == len(batches)
         runs[mode] = (losses, {k: v.detach().clone() for k, v in dm.transformer.state_dict().items()}, dm.Lt_count.clone(), tr.optimizer_state())
     monkeypatch.delenv("GSDD_TRAIN_GRAPH")
     np.testing.assert_allclose(runs["1"][0], runs["0"][0], rtol=2e-5)
