@@ -176,7 +176,7 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3, regime="f
                                       "launches_timed": n, "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                       "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                                       "frac_of_bf16_mfma_peak": round(3 * fl / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
-                                      "counters": profile_counters("d3pm_layer_h2_kernel<true;false>", None, regime) if full else None}
+                                      "counters": profile_counters("d3pm_layer_h2_kernel<true;false>", 256, regime) if full else None}
     ms, n = mean_ms("logits")
     fl = 2.0 * 64 * K * Mrows
     fam["logits"] = {"bound": "mfma (exact f32: v_mfma_f32_32x32x2_f32, the f32 datapath's own peak) / hbm write",
@@ -184,14 +184,14 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3, regime="f
                      "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                      "hbm_write_GBs": round(Mrows * K * 4.0 / ms / 1e6, 1), "hbm_frac": round(Mrows * K * 4.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "counters": profile_counters("d3pm_logits_kernel", None, regime) if full else None}
+                     "counters": profile_counters("d3pm_logits_kernel", 256, regime) if full else None}
     ms, n = mean_ms("step")
     by = 2.0 * M * K * 4
     fam["posterior_step"] = {"bound": "hbm (streams both logits copies once); the f32 vector issue port is what limits it",
                              "kernel": "d3pm_step_kernel", "ms_per_launch": round(ms, 4), "launches_timed": n,
                              "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
-                             "counters": profile_counters("d3pm_step_kernel", None, regime) if full else None}
+                             "counters": profile_counters("d3pm_step_kernel", (M + 3) // 4, regime) if full else None}
     # decode: the whole VQ-VAE decoder (implicit-GEMM convs), 221.0 GFLOP per 16x128x128 clip
     codes = torch.randint(0, K, (B,) + tuple(grid), device=device)
     vq.decode(codes)
@@ -210,7 +210,7 @@ def rooflines(dm, vq, cond, cf_cond, B, L, H, device, K, grid, reps=3, regime="f
                          "frac": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                          "frac_of_bf16_mfma_peak": round(6 * fl / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4),
                          # the decoder's dominant launch (the 256 -> 256 transposed-conv phases at 64x64 / 32x32)
-                         "counters": profile_counters("gemm_kernel<128;true;256;512>", None, regime)}
+                         "counters": profile_counters("gemm_kernel<128;true;256;512>", 2048, regime)}
     return roof, fam
 
 
@@ -306,7 +306,7 @@ def other_configs(args, dm, vq, device):
         tok = torch.randint(0, args.codes, (b4, L), generator=g).to(device)
         cond4 = torch.zeros(b4, 1, 512, device=device)               # the reference's zeroed text embedding (discrete_diffusion.py:25)
         losses = []
-        ts = timeit(lambda: losses.append(trainer.step(tok, cond4)), 2, 3)
+        ts = timeit(lambda: losses.append(trainer.step(tok, cond4)), 3, 3)          # (two eager steps, then the capture: replays from the fourth)
         ms = statistics.median(ts) * 1e3
         tflop = b4 * 0.278
         out["c4"] = {"workload": "C4 per GPU: D3PM training step, bs 16 (global 128 on 8 GPUs), 16x16x16 tokens, K=4096, 19 layers, "

@@ -24,13 +24,14 @@ copy("nearest.bygrid.csv", "nearest_code_kernel_stats.csv")
 copy("train.summary.csv", "d3pm_train_kernel_stats.csv")
 if os.path.exists(os.path.join(P, "vqtrain.summary.csv")):
     copy("vqtrain.summary.csv", "vqvae_train_kernel_stats.csv")
-BENCH = "python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline   (GSDD_TRAIN_GRAPH=0; the program started directly after `--`; tools/profile_round.sh)"
+BENCH = ("python3 bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-extra   (the program started directly after `--`; tools/profile_round.sh); "
+         "training kernels (attn_bwd_*; d3pm_train_bwd; rows_linear; wgrad; ln_bwd): the same passes over python3 tools/bench_train.py 16 4 with GSDD_TRAIN_GRAPH=0")
 copy("traffic.csv", "pmc_traffic.csv", (
     "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + BENCH + "; tools/make_traffic_csv.py",
     "one row per (kernel; grid size); counter unit KB; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950 (FETCH_SIZE reports half the bytes of wide coalesced reads: MI355X_MICROARCH.md section HBM; other access widths are uncalibrated).",
-    "the passes cover the headline loop (eager; one full batch of 2B = 32 rows: attention grid 8192; block 0 grid 4096), rooflines() and extra.configs: C5 per rank (attention grid 4096 / 2048 in two lanes of 4 clips), C4 (training forward attention grid 4096; attn_bwd_*; rows_linear; wgrad) and C2 (gemm_kernel; conv_wgrad; nearest_code_mfma at 262144 latents)."))
+    "the bench.py passes cover the headline loop (eager; one full batch of 2B = 32 rows: attention grid 8192; block 0 shared by the guidance copies: grid 4096) and rooflines(); the fused layer and logits kernels are persistent (grid 256 whatever the batch): only the headline shape runs in these passes."))
 copy("sq_bench.csv", "pmc_sq_counters.csv", (
-    "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -- " + BENCH + "; regime trained_like: the same with --no-extra --trained-like; tools/make_sq_csv.py",
+    "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -- " + BENCH + "; regime trained_like: the same with --trained-like; regime c4_training_step: tools/bench_train.py 16 4; tools/make_sq_csv.py",
     "means per dispatch; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over SQ_BUSY_CYCLES / 32 shader engines (= the dispatch's length in cycles); valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 over the same.",
     "bench.py reads `roofline.counters` and `extra.roofline_families[*].counters` from this file at run time (attention: the grid-8192 row = one full batch of 32 rows; 8.59e9 scores = 134.2 M wave-instruction slots of 64 scores)."))
 print("profiles written for", tag)

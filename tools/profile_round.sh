@@ -23,16 +23,27 @@ if [ "$1" = "traces" ]; then
   find "$O" -name "*.csv" -size +2M -delete
   exit 0
 fi
-export GSDD_TRAIN_GRAPH=0          # the PMC passes serialise dispatches: the training step runs launch by launch there
+# PMC passes.  Sampler kernels: bench.py ITSELF, headline shape only (--no-extra: the persistent kernels -- fused layer, logits -- launch
+# the same grid for every batch size, so other shapes in the same pass would blur their rows).  Training kernels (C4's): tools/bench_train.py,
+# launch by launch (GSDD_TRAIN_GRAPH=0: the PMC passes serialise dispatches anyway).
+export GSDD_TRAIN_GRAPH=0
 CTR="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
-BENCH="$R/bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline"
+BENCH="$R/bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-extra"
+TRAIN="$R/tools/bench_train.py 16 4"
+rm -rf "$O"/sq_train "$O"/fetch_train "$O"/write_train
 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$O/sqb_flat" -- python3 $BENCH > "$O/sqb_flat.log" 2>&1
-rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$O/sqb_trained" -- python3 $BENCH --no-extra --trained-like > "$O/sqb_trained.log" 2>&1
+rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$O/sqb_trained" -- python3 $BENCH --trained-like > "$O/sqb_trained.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -- python3 $BENCH > "$O/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -- python3 $BENCH > "$O/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$O/sq_train" -- python3 $TRAIN > "$O/sq_train.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch_train" -- python3 $TRAIN > "$O/fetch_train.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write_train" -- python3 $TRAIN > "$O/write_train.log" 2>&1
 unset GSDD_TRAIN_GRAPH
-KERNELS="d3pm_attention_v4 d3pm_layer_h2 d3pm_logits d3pm_step gemm_kernel axial_attention attn_bwd d3pm_train_bwd rows_linear wgrad_kernel conv_wgrad nearest_code_mfma"
-python3 "$R/tools/make_sq_csv.py" flat="$O/sqb_flat" trained_like="$O/sqb_trained" -- $KERNELS > "$O/sq_bench.csv"
-python3 "$R/tools/make_traffic_csv.py" "$O/fetch" "$O/write" $KERNELS > "$O/traffic.csv"
+SAMPLER="d3pm_attention_v4 d3pm_layer_h2 d3pm_logits d3pm_step gemm_kernel axial_attention"
+TRAINK="attn_bwd d3pm_train_bwd rows_linear wgrad_kernel d3pm_attention_v4 ln_bwd gelu2"
+python3 "$R/tools/make_sq_csv.py" flat="$O/sqb_flat" trained_like="$O/sqb_trained" -- $SAMPLER > "$O/sq_bench.csv"
+python3 "$R/tools/make_sq_csv.py" c4_training_step="$O/sq_train" -- $TRAINK | tail -n +2 >> "$O/sq_bench.csv"
+python3 "$R/tools/make_traffic_csv.py" "$O/fetch" "$O/write" $SAMPLER > "$O/traffic.csv"
+python3 "$R/tools/make_traffic_csv.py" "$O/fetch_train" "$O/write_train" attn_bwd d3pm_train_bwd rows_linear wgrad_kernel ln_bwd | tail -n +2 >> "$O/traffic.csv"
 # keep the transfer small: the raw traces stay on the box
 find "$O" -name "*.csv" -size +2M -delete
