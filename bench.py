@@ -343,6 +343,30 @@ def other_configs(args, dm, vq, device):
     except Exception as e:                                           # noqa: BLE001
         out["c2"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
+
+    try:                                                             # ---- the reference's shipped default length, L = 1024
+        sargs = argparse.Namespace(**vars(args))
+        sargs.grid = [4, 16, 16]                                     # content_seq_len 1024 (diffusion_transformer.yaml:8 there), clips of 4 x 128 x 128
+        dms, vqs, Ls = build_models(sargs, device)
+        bs = args.batch
+        gs = torch.Generator().manual_seed(7)
+        conds = torch.randn(bs, 1, 512, generator=gs).to(device)
+        cfs = torch.zeros_like(conds)
+        dms.set_noise(1234, 0)
+
+        def pass_s():
+            o = dms.sample(["synthetic"] * bs, None, conds, cfs, content_token=None, filter_ratio=0)
+            return vqs.decode(o["content_token"].view(bs, *sargs.grid))
+        ts = timeit(pass_s, 1, 2)
+        out["shipped_default_L1024"] = {"workload": "the reference's shipped sequence length: 100 guided steps over 1024 tokens (4x16x16 grid), bs "
+                                                    f"{bs}, 19 layers, K={args.codes}, + decode to 3x4x128x128 (cpu_baseline.shipped_default_L1024 is the "
+                                                    "oracle at this length)",
+                                        "value": round(bs / statistics.mean(ts), 3), "unit": "videos/s", "s_per_pass": [round(t, 4) for t in ts],
+                                        "sampler_lanes": dms._last_lanes}
+        del dms, vqs
+    except Exception as e:                                           # noqa: BLE001
+        out["shipped_default_L1024"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
     return out
 
 

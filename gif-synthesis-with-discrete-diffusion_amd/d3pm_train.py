@@ -261,7 +261,7 @@ class D3PMTrainer:
                 g[pre + f"attn1.{nm}.bias"] = bq[j * D:(j + 1) * D]
             del g[pre + "_wqkv"], g[pre + "_bqkv"]
             dhn = lin_t(dqkv, "qkv_t", lay["wqkv"], D)
-            dtab = torch.zeros((B, 2 * D), **f)
+            dtab = self._arena.zeros((B, 2 * D))          # (scratch, not a gradient: it rides in the arena for its one zero fill per step)
             dx = ops.ln_bwd(dhn, s["x_in"], s["stats1"], lay["ada1"].view(-1), sel=t, gstride=2 * D, rows_per_batch=L,
                             dx_in=dx1, dgamma=dtab, dbeta=dtab.view(-1)[D:], gacc_stride=2 * D, acc_by_batch=True)
             ops.adaln_bwd(dtab, t, blk.ln1.emb.weight.contiguous(), blk.ln1.linear.weight.contiguous(),
