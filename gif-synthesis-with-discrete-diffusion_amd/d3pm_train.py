@@ -261,7 +261,7 @@ class D3PMTrainer:
                 g[pre + f"attn1.{nm}.bias"] = bq[j * D:(j + 1) * D]
             del g[pre + "_wqkv"], g[pre + "_bqkv"]
             dhn = lin_t(dqkv, "qkv_t", lay["wqkv"], D)
-            dtab = self._arena.zeros((B, 2 * D))          # (scratch, not a gradient: it rides in the arena for its one zero fill per step)
+            dtab = torch.zeros((B, 2 * D), **f)           # (not in the arena: the arena's size must not depend on the batch size)
             dx = ops.ln_bwd(dhn, s["x_in"], s["stats1"], lay["ada1"].view(-1), sel=t, gstride=2 * D, rows_per_batch=L,
                             dx_in=dx1, dgamma=dtab, dbeta=dtab.view(-1)[D:], gacc_stride=2 * D, acc_by_batch=True)
             ops.adaln_bwd(dtab, t, blk.ln1.emb.weight.contiguous(), blk.ln1.linear.weight.contiguous(),
@@ -341,9 +341,11 @@ class D3PMTrainer:
     def _step_graphed(self, x0, cond, t, pt):
         """Two eager steps first (arenas, images and tables reach their final addresses), then capture, then replays."""
         self._eager_steps = getattr(self, "_eager_steps", 0)
-        st = getattr(self, "_graph", None)
-        if st is not None and (st["shape"] != (tuple(x0.shape), tuple(cond.shape)) or st["lr"] != self.lr):
-            st = self._graph = None                              # another batch shape or learning rate: capture again
+        # one captured graph per (batch shape, learning rate), the two most recent kept: an epoch's short last batch must not make
+        # every epoch capture twice (each graph owns its activations' pool: ~7 GB at bs 16, L = 4096)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        key = (tuple(x0.shape), tuple(cond.shape), float(self.lr))
+        st = self._graph = graphs.get(key)
         if st is None and self._eager_steps < 2:
             self._eager_steps += 1
             return self._step_eager(x0, cond, t, pt)
@@ -352,6 +354,9 @@ class D3PMTrainer:
             keep = (dm.noise_stream, self._adam.step_count)
             try:
                 st = self._graph = self._capture(x0, cond)
+                while len(graphs) >= 2:
+                    graphs.pop(next(iter(graphs)))
+                graphs[key] = st
             except Exception as e:                                # noqa: BLE001  (a capture that cannot be made must not cost the step)
                 import warnings
                 warnings.warn(f"D3PMTrainer: the training step could not be captured as a graph ({type(e).__name__}: {e}); running launch by launch")
@@ -402,7 +407,7 @@ class D3PMTrainer:
         return a.state() if a is not None else getattr(self, "_pending_adam", None)
 
     def load_optimizer_state(self, state):
-        self._graph = None                                      # the captured step holds Adam's step count on the device
+        self._graph, self._graphs = None, {}                    # (captured steps bake the addresses of the Adam state they were made with)
         if state is None:
             return
         if getattr(self, "_adam", None) is not None:

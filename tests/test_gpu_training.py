@@ -222,6 +222,13 @@ def test_captured_training_step_equals_the_eager_steps(G, golden, monkeypatch):
         assert dm.noise_stream == 3 + 3 + len(batches) and tr._adam.step_count == len(batches)
         runs[mode] = (losses, {k: v.detach().clone() for k, v in dm.transformer.state_dict().items()}, dm.Lt_count.clone(), tr.optimizer_state())
     monkeypatch.delenv("GSDD_TRAIN_GRAPH")
+    # a short batch (an epoch's last one) gets its own captured graph, and the full-size graph is still there afterwards
+    x0s, conds, ts, pts = (z[:1].contiguous() for z in batches[0])
+    g_full = tr._graph
+    tr.step(x0s, conds, t=ts, pt=pts)
+    assert tr._graph is not g_full and len(tr._graphs) == 2
+    tr.step(*batches[1][:2], t=batches[1][2], pt=batches[1][3])
+    assert tr._graph is g_full
     np.testing.assert_allclose(runs["1"][0], runs["0"][0], rtol=2e-5)
     for k, w in runs["0"][1].items():
         if k.endswith("attn1.key.bias"):              # softmax is shift invariant: this gradient is mathematically zero, what arrives is
