@@ -416,7 +416,7 @@ int gsdd_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
  * block b; the caller chops every parameter into such chunks. */
 int gsdd_adam_multi(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, int step, void* stream);
 /* ... with the step count (>= 1) read from device memory at execution time: the form a captured, replayed training step uses (the
- * caller advances *step_dev with gsdd_advance inside the same graph). */
+ * caller sets *step_dev before each replay, or advances it with gsdd_advance inside the graph). */
 int gsdd_adam_multi_dev(const int64_t* table, int n_blocks, float lr, float beta1, float beta2, float eps, const int64_t* step_dev,
                         void* stream);
 
