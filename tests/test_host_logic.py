@@ -546,3 +546,25 @@ def test_host_side_of_the_c_abi_under_address_and_ub_sanitizers():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "0 failed" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_reads_occupancy_counters_of_its_own_grid_from_the_committed_profile():
+    """bench.py's `roofline.counters` / `extra.roofline_families[*].counters` are read from profiles/r*_pmc_sq_counters.csv (a --pmc pass
+    over bench.py itself) for the kernel, the weight regime and the bench shape's grid; older files in the per-variant layout of rounds
+    1-3 are skipped; an unknown kernel gives None."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    flat = bench.profile_counters("d3pm_attention_v4_kernel<384, 8>", 8192, "flat")
+    trained = bench.profile_counters("d3pm_attention_v4_kernel<384, 8>", 8192, "trained_like")
+    assert flat is not None and flat["source"].endswith("_pmc_sq_counters.csv") and flat["grid_workgroups"] == 8192
+    # the attention kernel is bound by vector issue, not by the matrix pipe; trained-like rows spend more instructions per score
+    assert 0.7 < flat["valu_issue_busy"] < 1.0 and 0.2 < flat["mfma_busy"] < 0.5
+    assert trained["valu_insts_per_dispatch"] > flat["valu_insts_per_dispatch"]
+    step = bench.profile_counters("d3pm_step_kernel", 16384, "flat")
+    assert step["mfma_busy"] == 0.0 and step["valu_issue_busy"] > 0.9
+    assert bench.profile_counters("d3pm_logits_kernel", 256, "flat")["mfma_busy"] > 0.6
+    assert bench.profile_counters("no_such_kernel", None, "flat") is None
+    assert bench.profile_counters("d3pm_attention_v4_kernel<384, 8>", 12345, "flat") is None
